@@ -1,0 +1,106 @@
+"""ctypes wrapper over oracle/libsf_oracle.so.  TEST INFRASTRUCTURE ONLY (see sf_oracle.c header).
+
+Imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg — never by scanfold_amd.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libsf_oracle.so")
+_lib = None
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(
+            os.path.join(_HERE, "sf_oracle.c")):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            build()
+        L = ctypes.CDLL(_LIB)
+        L.sfo_set_params.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+        L.sfo_mfe.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_char_p]
+        L.sfo_mfe_batch.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+        L.sfo_eval.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+        L.sfo_brute.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
+                                ctypes.POINTER(ctypes.c_double), ctypes.c_void_p,
+                                ctypes.POINTER(ctypes.c_longlong)]
+        L.sfo_pf.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.c_void_p,
+                             ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+        _lib = L
+    return _lib
+
+
+def set_params(paramset):
+    blob = paramset.blob()
+    assert len(blob) == lib().sfo_params_size(), (len(blob), lib().sfo_params_size())
+    rc = lib().sfo_set_params(blob, len(blob))
+    if rc:
+        raise RuntimeError("sfo_set_params rc=%d" % rc)
+
+
+def mfe(seq, structure=True):
+    s = seq.encode()
+    e = ctypes.c_int()
+    buf = ctypes.create_string_buffer(len(s) + 1) if structure else None
+    rc = lib().sfo_mfe(s, len(s), ctypes.byref(e), buf)
+    if rc:
+        raise RuntimeError("sfo_mfe rc=%d" % rc)
+    return (buf.value.decode() if structure else None), e.value
+
+
+def mfe_batch(seqs, nthreads=0):
+    """seqs: list of equal-length str, or uint8 array (n, W) of ASCII. Returns int32 array (dcal/mol)."""
+    if isinstance(seqs, np.ndarray):
+        arr = np.ascontiguousarray(seqs, dtype=np.uint8)
+    else:
+        arr = np.frombuffer("".join(seqs).encode(), dtype=np.uint8).reshape(len(seqs), -1)
+    n, W = arr.shape
+    out = np.empty(n, dtype=np.int32)
+    rc = lib().sfo_mfe_batch(arr.ctypes.data_as(ctypes.c_char_p), n, W, out.ctypes.data, nthreads)
+    if rc:
+        raise RuntimeError("sfo_mfe_batch rc=%d" % rc)
+    return out
+
+
+def eval_structure(seq, db):
+    e = ctypes.c_int()
+    rc = lib().sfo_eval(seq.encode(), db.encode(), len(seq), ctypes.byref(e))
+    if rc:
+        raise RuntimeError("sfo_eval rc=%d" % rc)
+    return e.value
+
+
+def brute(seq, want_bpp=False):
+    n = len(seq)
+    e = ctypes.c_int()
+    Z = ctypes.c_double()
+    cnt = ctypes.c_longlong()
+    bpp = np.zeros((n + 1, n + 1)) if want_bpp else None
+    rc = lib().sfo_brute(seq.encode(), n, ctypes.byref(e), ctypes.byref(Z),
+                         bpp.ctypes.data if want_bpp else None, ctypes.byref(cnt))
+    if rc:
+        raise RuntimeError("sfo_brute rc=%d" % rc)
+    return e.value, Z.value, bpp, cnt.value
+
+
+def pf(seq, want_bpp=False):
+    """-> dict(dG, centroid, centroid_dist, mean_bp_dist, bpp)"""
+    n = len(seq)
+    dG = ctypes.c_double()
+    cd = ctypes.c_double()
+    mbd = ctypes.c_double()
+    cen = ctypes.create_string_buffer(n + 1)
+    bpp = np.zeros((n + 1, n + 1)) if want_bpp else None
+    rc = lib().sfo_pf(seq.encode(), n, ctypes.byref(dG), bpp.ctypes.data if want_bpp else None, cen,
+                      ctypes.byref(cd), ctypes.byref(mbd))
+    if rc:
+        raise RuntimeError("sfo_pf rc=%d" % rc)
+    return dict(dG=dG.value, centroid=cen.value.decode(), centroid_dist=cd.value, mean_bp_dist=mbd.value, bpp=bpp)

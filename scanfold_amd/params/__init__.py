@@ -1,0 +1,222 @@
+"""Energy-parameter sets: ViennaRNA ".par" v2.0 text -> the binary blob of include/sf_params_blob.h.
+
+The reference never reads parameters itself; they live inside ViennaRNA, reached through
+`RNA.md()` / `RNA.fold_compound(seq, md)` (ScanFold-Scan.py:70-71,382; ScanFoldFunctions.py:776-786).
+Here they are plain data handed to `sf_params_load` (include/scanfold_hip.h).
+
+`default_params()` loads the reconstructed set shipped in this directory (see
+tools/make_recon_par.py for its provenance: parity vs ViennaRNA's own table is unpinned);
+`load_par(path)` reads any file in the same text format, e.g. a real `rna_turner2004.par`.
+"""
+import itertools
+import os
+import re
+
+import numpy as np
+
+INF = 10000000
+MAX_SPECIAL = 40
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_PAR = os.path.join(_HERE, "rna_turner2004_recon.par")
+
+# numpy mirror of struct sf_params_blob (include/sf_params_blob.h); align=True follows the C ABI
+BLOB_DTYPE = np.dtype([
+    ("magic", "<u4"), ("version", "<u4"),
+    ("temperature", "<f8"), ("lxc", "<f8"),
+    ("stack", "<i4", (8, 8)),
+    ("hairpin", "<i4", (31,)), ("bulge", "<i4", (31,)), ("internal_loop", "<i4", (31,)),
+    ("mismatchI", "<i4", (8, 5, 5)), ("mismatchH", "<i4", (8, 5, 5)), ("mismatchM", "<i4", (8, 5, 5)),
+    ("mismatch1nI", "<i4", (8, 5, 5)), ("mismatch23I", "<i4", (8, 5, 5)), ("mismatchExt", "<i4", (8, 5, 5)),
+    ("dangle5", "<i4", (8, 5)), ("dangle3", "<i4", (8, 5)),
+    ("int11", "<i4", (8, 8, 5, 5)),
+    ("int21", "<i4", (8, 8, 5, 5, 5)),
+    ("int22", "<i4", (8, 8, 5, 5, 5, 5)),
+    ("ninio", "<i4"), ("max_ninio", "<i4"),
+    ("MLbase", "<i4"), ("MLclosing", "<i4"), ("MLintern", "<i4", (8,)),
+    ("TerminalAU", "<i4"), ("DuplexInit", "<i4"),
+    ("n_tetra", "<i4"), ("n_tri", "<i4"), ("n_hexa", "<i4"), ("pad0", "<i4"),
+    ("tetra_seq", "S8", (MAX_SPECIAL,)), ("tetra_E", "<i4", (MAX_SPECIAL,)),
+    ("tri_seq", "S8", (MAX_SPECIAL,)), ("tri_E", "<i4", (MAX_SPECIAL,)),
+    ("hexa_seq", "S12", (MAX_SPECIAL,)), ("hexa_E", "<i4", (MAX_SPECIAL,)),
+], align=True)
+
+MAGIC = 0x31504653
+VERSION = 1
+
+_MM_SECTIONS = {
+    "mismatch_hairpin": "mismatchH", "mismatch_interior": "mismatchI",
+    "mismatch_interior_1n": "mismatch1nI", "mismatch_interior_23": "mismatch23I",
+    "mismatch_multi": "mismatchM", "mismatch_exterior": "mismatchExt",
+}
+
+
+class ParamSet:
+    """One parameter set; `.rec` is a numpy record with the fields of sf_params_blob."""
+
+    def __init__(self, rec, source):
+        self.rec = rec
+        self.source = source
+
+    def blob(self):
+        return self.rec.tobytes()
+
+    @property
+    def temperature(self):
+        return float(self.rec["temperature"])
+
+    def copy(self):
+        return ParamSet(self.rec.copy(), self.source)
+
+
+def _tok_int(t):
+    if t == "INF":
+        return INF
+    if t == "-INF":
+        return -INF
+    if t == "DEF":
+        raise ValueError("DEF entries are not supported (no compiled-in defaults to fall back on)")
+    return int(t)
+
+
+def parse_par_text(text, source="<string>"):
+    if not text.lstrip().startswith("## RNAfold parameter file v2.0"):
+        raise ValueError("%s: not a 'RNAfold parameter file v2.0'" % source)
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    sections = {}
+    cur = None
+    for line in text.splitlines():
+        line = line.strip()
+        if not line or line.startswith("##"):
+            continue
+        if line.startswith("#"):
+            cur = line[1:].strip()
+            if cur == "END":
+                break
+            sections[cur] = []
+            continue
+        if cur is not None:
+            sections[cur].append(line)
+
+    rec = np.zeros((), dtype=BLOB_DTYPE)
+    rec["magic"] = MAGIC
+    rec["version"] = VERSION
+    rec["temperature"] = 37.0
+
+    def ints(name, n):
+        toks = " ".join(sections[name]).split()
+        if len(toks) != n:
+            raise ValueError("%s: section '%s' has %d values, expected %d" % (source, name, len(toks), n))
+        return np.array([_tok_int(t) for t in toks], dtype=np.int64)
+
+    need = ["stack", "hairpin", "bulge", "interior", "dangle5", "dangle3", "int11", "int21", "int22",
+            "NINIO", "ML_params", "Misc"] + list(_MM_SECTIONS)
+    missing = [s for s in need if s not in sections]
+    if missing:
+        raise ValueError("%s: missing sections %s" % (source, missing))
+
+    rec["stack"][1:8, 1:8] = ints("stack", 49).reshape(7, 7)
+    for sec, field in _MM_SECTIONS.items():
+        rec[field][1:8] = ints(sec, 175).reshape(7, 5, 5)
+    rec["dangle5"][1:8] = ints("dangle5", 35).reshape(7, 5)
+    rec["dangle3"][1:8] = ints("dangle3", 35).reshape(7, 5)
+    rec["int11"][1:8, 1:8] = ints("int11", 49 * 25).reshape(7, 7, 5, 5)
+    rec["int21"][1:8, 1:8] = ints("int21", 49 * 125).reshape(7, 7, 5, 5, 5)
+    core = ints("int22", 36 * 256).reshape(6, 6, 4, 4, 4, 4)
+    i22 = np.zeros((8, 8, 5, 5, 5, 5), dtype=np.int64)
+    i22[1:7, 1:7, 1:5, 1:5, 1:5, 1:5] = core
+    # entries with an unknown base (index 0) / non-standard pair (7): least stabilising known entry
+    for ax in (2, 3, 4, 5):
+        sl = [slice(None)] * 6
+        sl[ax] = slice(1, 5)
+        dst = [slice(None)] * 6
+        dst[ax] = 0
+        i22[tuple(dst)] = i22[tuple(sl)].max(axis=ax)
+    i22[7, :] = i22[1:7, :].max(axis=0)
+    i22[:, 7] = i22[:, 1:7].max(axis=1)
+    i22[0, :] = 0
+    i22[:, 0] = 0
+    rec["int22"] = i22
+    rec["hairpin"] = ints("hairpin", 31)
+    rec["bulge"] = ints("bulge", 31)
+    rec["internal_loop"] = ints("interior", 31)
+    nin = " ".join(sections["NINIO"]).split()
+    rec["ninio"] = _tok_int(nin[0])
+    rec["max_ninio"] = _tok_int(nin[2])
+    ml = " ".join(sections["ML_params"]).split()
+    rec["MLbase"] = _tok_int(ml[0])
+    rec["MLclosing"] = _tok_int(ml[2])
+    rec["MLintern"][:] = _tok_int(ml[4])
+    misc = " ".join(sections["Misc"]).split()
+    rec["DuplexInit"] = _tok_int(misc[0])
+    rec["TerminalAU"] = _tok_int(misc[2])
+    rec["lxc"] = float(misc[4]) if len(misc) > 4 else 107.856
+
+    for sec, fseq, fe, fn, ln in (("Tetraloops", "tetra_seq", "tetra_E", "n_tetra", 6),
+                                  ("Triloops", "tri_seq", "tri_E", "n_tri", 5),
+                                  ("Hexaloops", "hexa_seq", "hexa_E", "n_hexa", 8)):
+        k = 0
+        for line in sections.get(sec, []):
+            parts = line.split()
+            if len(parts) < 2:
+                continue
+            if len(parts[0]) != ln:
+                raise ValueError("%s: %s entry '%s' must have %d characters" % (source, sec, parts[0], ln))
+            if k >= MAX_SPECIAL:
+                raise ValueError("%s: more than %d %s" % (source, MAX_SPECIAL, sec))
+            rec[fseq][k] = parts[0].encode()
+            rec[fe][k] = _tok_int(parts[1])
+            k += 1
+        rec[fn] = k
+    return ParamSet(rec, source)
+
+
+def load_par(path):
+    with open(path, "r") as f:
+        return parse_par_text(f.read(), source=path)
+
+
+_default = None
+
+
+def default_params():
+    global _default
+    if _default is None:
+        _default = load_par(DEFAULT_PAR)
+    return _default.copy()
+
+
+def random_params(seed, scale=200):
+    """A randomised but symmetry-respecting set for index-order tests (oracle vs HIP vs evaluator).
+
+    Keeps loop-initiation arrays / constants of the default set and replaces every sequence-dependent
+    table by random integers, honouring stack[a][b]==stack[b][a],
+    int11[a][b][x][y]==int11[b][a][y][x], int22[a][b][w][x][y][z]==int22[b][a][y][z][w][x]
+     — the symmetries a loop read from either strand relies on.
+    """
+    rng = np.random.default_rng(seed)
+    p = default_params()
+    r = p.rec
+
+    def rnd(shape, lo=-scale, hi=scale):
+        return rng.integers(lo, hi, size=shape)
+
+    st = rnd((8, 8), -350, 50)
+    st = np.minimum(st, st.T)
+    r["stack"] = st
+    for f in ("mismatchI", "mismatchH", "mismatchM", "mismatch1nI", "mismatch23I", "mismatchExt"):
+        r[f] = rnd((8, 5, 5), -250, 60)
+    r["dangle5"] = rnd((8, 5), -120, 0)
+    r["dangle3"] = rnd((8, 5), -180, 0)
+    a = rnd((8, 8, 5, 5), -100, 300)
+    r["int11"] = np.minimum(a, a.transpose(1, 0, 3, 2))
+    r["int21"] = rnd((8, 8, 5, 5, 5), 50, 500)
+    b = rnd((8, 8, 5, 5, 5, 5), -50, 400)
+    r["int22"] = np.minimum(b, b.transpose(1, 0, 4, 5, 2, 3))
+    for f in ("tetra_E", "tri_E", "hexa_E"):
+        r[f] = rnd((MAX_SPECIAL,), 100, 700)
+    r["TerminalAU"] = int(rng.integers(20, 90))
+    r["MLbase"] = int(rng.integers(0, 3)) * 10
+    r["MLintern"][:] = int(rng.integers(-120, -30))
+    r["MLclosing"] = int(rng.integers(300, 1100))
+    p.source = "random_params(%d)" % seed
+    return p

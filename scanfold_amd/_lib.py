@@ -1,0 +1,189 @@
+"""ctypes binding of libscanfold_hip.so (include/scanfold_hip.h) — the only compute path of this package.
+
+There is no CPU fallback: if the shared library is missing or no GPU is usable, `get_engine()` raises.
+(The reference's compute path is ViennaRNA on the CPU through a 12-process pool,
+ScanFold-Scan.py:73-77,244-262; nothing of it is kept.)
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import params as _params
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libscanfold_hip.so")
+
+SHUFFLE_MONO = 0
+SHUFFLE_DI = 1
+SCAN_NO_PF = 1
+SCAN_NO_TRACE = 2
+
+_c_u8p = ctypes.c_void_p
+_EXPORTS = {
+    "sf_strerror": (ctypes.c_char_p, [ctypes.c_int]),
+    "sf_last_hip_error": (ctypes.c_char_p, []),
+    "sf_init": (ctypes.c_int, [ctypes.c_int]),
+    "sf_shutdown": (ctypes.c_int, []),
+    "sf_device_name": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_size_t]),
+    "sf_params_load": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_double]),
+    "sf_mfe_batch": (ctypes.c_int, [_c_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "sf_mfe_batch_dev": (ctypes.c_int, [_c_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+    "sf_mfe_trace_batch": (ctypes.c_int, [_c_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+    "sf_pf_batch": (ctypes.c_int, [_c_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                   ctypes.c_void_p, ctypes.c_void_p]),
+    "sf_shuffle_windows": (ctypes.c_int, [_c_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint64,
+                                          ctypes.c_void_p]),
+    "sf_scan": (ctypes.c_int, [_c_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                               ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint, ctypes.c_void_p,
+                               ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "sf_scan_dev": (ctypes.c_int, [_c_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                   ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint, ctypes.c_void_p,
+                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                   ctypes.c_void_p]),
+    "sf_prof_reset": (ctypes.c_int, []),
+    "sf_prof_get": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64),
+                                   ctypes.POINTER(ctypes.c_int64)]),
+}
+EXPORTED_SYMBOLS = tuple(_EXPORTS)
+
+
+class ScanFoldHipError(RuntimeError):
+    pass
+
+
+def load_library(path=LIB_PATH):
+    """dlopen the C-ABI library and declare every prototype; raises if it or a symbol is missing."""
+    if not os.path.exists(path):
+        raise ScanFoldHipError(
+            "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in _EXPORTS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+def seqs_to_array(seqs, W=None):
+    """list of equal-length str / bytes, or a uint8 (n, W) array -> contiguous uint8 (n, W)."""
+    if isinstance(seqs, np.ndarray):
+        arr = np.ascontiguousarray(seqs, dtype=np.uint8)
+        if arr.ndim != 2:
+            raise ValueError("sequence array must be 2-D (n, W)")
+        return arr
+    seqs = [s if isinstance(s, (bytes, bytearray)) else str(s).encode("ascii") for s in seqs]
+    if not seqs:
+        return np.zeros((0, W or 1), dtype=np.uint8)
+    W = len(seqs[0])
+    if any(len(s) != W for s in seqs):
+        raise ValueError("all sequences of one batch must have the same length")
+    return np.frombuffer(b"".join(seqs), dtype=np.uint8).reshape(len(seqs), W)
+
+
+class Engine:
+    """One process, one GPU.  Thin, stateful wrapper over the C ABI."""
+
+    def __init__(self, device=0, paramset=None, lib_path=LIB_PATH):
+        self.lib = load_library(lib_path)
+        self._check(self.lib.sf_init(int(device)))
+        self.device = int(device)
+        self.params = None
+        self.load_params(paramset if paramset is not None else _params.default_params())
+
+    # -- plumbing --
+    def _check(self, rc):
+        if rc != 0:
+            msg = self.lib.sf_strerror(rc).decode()
+            if rc == -6:
+                msg += ": " + self.lib.sf_last_hip_error().decode()
+            raise ScanFoldHipError(msg)
+
+    def device_name(self):
+        buf = ctypes.create_string_buffer(256)
+        self._check(self.lib.sf_device_name(buf, 256))
+        return buf.value.decode()
+
+    def load_params(self, paramset, temperature=None):
+        blob = paramset.blob()
+        t = paramset.temperature if temperature is None else float(temperature)
+        self._check(self.lib.sf_params_load(blob, len(blob), t))
+        self.params = paramset
+
+    def shutdown(self):
+        self._check(self.lib.sf_shutdown())
+
+    # -- host-buffer entry points --
+    def mfe_batch(self, seqs):
+        arr = seqs_to_array(seqs)
+        n, W = arr.shape
+        out = np.empty(n, dtype=np.int32)
+        self._check(self.lib.sf_mfe_batch(arr.ctypes.data, n, W, out.ctypes.data))
+        return out
+
+    def mfe_trace_batch(self, seqs):
+        arr = seqs_to_array(seqs)
+        n, W = arr.shape
+        out = np.empty(n, dtype=np.int32)
+        db = np.zeros((n, W + 1), dtype=np.uint8)
+        self._check(self.lib.sf_mfe_trace_batch(arr.ctypes.data, n, W, out.ctypes.data, db.ctypes.data))
+        return out, [bytes(row[:W]).decode() for row in db]
+
+    def pf_batch(self, seqs):
+        arr = seqs_to_array(seqs)
+        n, W = arr.shape
+        dG = np.empty(n)
+        mbd = np.empty(n)
+        cd = np.empty(n)
+        cen = np.zeros((n, W + 1), dtype=np.uint8)
+        self._check(self.lib.sf_pf_batch(arr.ctypes.data, n, W, dG.ctypes.data, mbd.ctypes.data, cen.ctypes.data,
+                                         cd.ctypes.data))
+        return dict(dG=dG, mean_bp_dist=mbd, centroid=[bytes(r[:W]).decode() for r in cen], centroid_dist=cd)
+
+    def shuffle_windows(self, transcript, W, step, win_begin, n_win, r, kind, seed):
+        tr = np.frombuffer(transcript.encode("ascii") if isinstance(transcript, str) else bytes(transcript),
+                           dtype=np.uint8)
+        out = np.empty((n_win * (r + 1), W), dtype=np.uint8)
+        self._check(self.lib.sf_shuffle_windows(tr.ctypes.data, len(tr), W, step, win_begin, n_win, r, kind,
+                                                ctypes.c_uint64(seed), out.ctypes.data))
+        return out
+
+    def scan(self, transcript, W, step, win_begin, n_win, r, kind, seed, flags=0):
+        """-> dict(energies int32 (n_win, r+1), structure [str], centroid [str], ens_div, ens_dG)"""
+        tr = np.frombuffer(transcript.encode("ascii") if isinstance(transcript, str) else bytes(transcript),
+                           dtype=np.uint8)
+        en = np.empty((n_win, r + 1), dtype=np.int32)
+        db = np.zeros((n_win, W + 1), dtype=np.uint8)
+        cen = np.zeros((n_win, W + 1), dtype=np.uint8)
+        div = np.zeros(n_win)
+        dG = np.zeros(n_win)
+        self._check(self.lib.sf_scan(tr.ctypes.data, len(tr), W, step, win_begin, n_win, r, kind,
+                                     ctypes.c_uint64(seed), flags, en.ctypes.data, db.ctypes.data, cen.ctypes.data,
+                                     div.ctypes.data, dG.ctypes.data))
+        return dict(energies=en, structure=[bytes(x[:W]).decode() for x in db],
+                    centroid=[bytes(x[:W]).decode() for x in cen], ens_div=div, ens_dG=dG)
+
+    def prof_reset(self):
+        self._check(self.lib.sf_prof_reset())
+
+    def prof_get(self):
+        ms = ctypes.c_double()
+        nl = ctypes.c_int64()
+        nf = ctypes.c_int64()
+        self._check(self.lib.sf_prof_get(ctypes.byref(ms), ctypes.byref(nl), ctypes.byref(nf)))
+        return ms.value, nl.value, nf.value
+
+
+_engine = None
+
+
+def get_engine(device=None):
+    """Process-wide engine on LOCAL_RANK's GPU (or `device`)."""
+    global _engine
+    if _engine is None:
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        _engine = Engine(device=device)
+    return _engine

@@ -1,0 +1,515 @@
+// scanfold_hip.hip — host side of libscanfold_hip.so: the C ABI of include/scanfold_hip.h over the HIP kernels.
+//
+// The reference drives this path from Python with a 12-process pool created per call
+// (ScanFold-Scan.py:73-77,256,274); here one process owns one GPU and every call is a few batched launches
+// on one HIP stream.  No CPU compute path exists in this file: without a GPU sf_init fails.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "sf_launch.h"
+#include "sf_energy.h"
+#include "sf_mfe_full.hip.h"
+#include "sf_mfe_fast.hip.h"
+#include "sf_pf.hip.h"
+#include "sf_shuffle.hip.h"
+
+namespace {
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+};
+
+struct Ctx {
+  bool init = false;
+  bool have_params = false;
+  int dev = 0;
+  int n_cu = 0;
+  std::string dev_name;
+  hipStream_t stream = nullptr;
+  SfDevParams *dP = nullptr;
+  SfDevParamsPF *dX = nullptr;
+  SfFastParams *dF = nullptr;
+  double temperature = 37.0;
+  DevBuf full_scratch, pf_scratch, fast_scratch, seqs, energies, db, cen, dbl, status, transcript, ovf;
+  std::string last_hip_error;
+  // profiling of the dominant kernel
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+  double prof_ms = 0.0;
+  int64_t prof_launches = 0, prof_folds = 0;
+  int force_full = 0;
+} g;
+
+#define HIPCHK(call)                                                              \
+  do {                                                                            \
+    hipError_t e_ = (call);                                                       \
+    if (e_ != hipSuccess) {                                                       \
+      char b_[512];                                                               \
+      snprintf(b_, sizeof b_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+      g.last_hip_error = b_;                                                      \
+      return SF_ERR_HIP;                                                          \
+    }                                                                             \
+  } while (0)
+
+int ensure(DevBuf &b, size_t need) {
+  if (need <= b.cap) return SF_OK;
+  if (b.p) HIPCHK(hipFree(b.p));
+  b.p = nullptr;
+  b.cap = 0;
+  size_t cap = need + need / 8 + 256;
+  HIPCHK(hipMalloc(&b.p, cap));
+  b.cap = cap;
+  return SF_OK;
+}
+
+int block_threads(int W) {
+  int t = ((W + 63) / 64) * 64;
+  return t < 64 ? 64 : t;
+}
+
+int check_ready() {
+  if (!g.init) return SF_ERR_NOT_INIT;
+  if (!g.have_params) return SF_ERR_NO_PARAMS;
+  return SF_OK;
+}
+
+double smooth_term(double x) {  // ViennaRNA's SMOOTH() with pf_smooth=1
+  const double SCALE = 10.0;
+  if (x / SCALE < -1.2283697) return 0.0;
+  if (x / SCALE > 0.8660254) return x;
+  const double s = sin(x / SCALE - 0.34242663) + 1.0;
+  return SCALE * 0.38490018 * s * s;
+}
+
+uint32_t pack_key(const char *s, int len) {
+  uint32_t k = 0;
+  for (int i = 0; i < len; i++) k = (k << 3) | sf_encode_nt((uint8_t)s[i]);
+  return k;
+}
+
+void build_dev_params(const sf_params_blob &P, SfDevParams &D, SfDevParamsPF &X) {
+  memset(&D, 0, sizeof D);
+  D.P = P;
+  for (int s = 0; s <= SF_MAX_W + 1; s++)
+    D.hp_init[s] = (s <= 30) ? P.hairpin[s] : P.hairpin[30] + (int)(P.lxc * log(s / 30.));
+  for (int k = 0; k < SF_NSPECIAL; k++) {
+    D.tetra_key[k] = k < P.n_tetra ? pack_key(P.tetra_seq[k], 6) : 0xFFFFFFFFu;
+    D.tri_key[k] = k < P.n_tri ? pack_key(P.tri_seq[k], 5) : 0xFFFFFFFFu;
+    D.hexa_key[k] = k < P.n_hexa ? pack_key(P.hexa_seq[k], 8) : 0xFFFFFFFFu;
+  }
+  D.pair[2][3] = 1; D.pair[3][2] = 2; D.pair[3][4] = 3; D.pair[4][3] = 4; D.pair[1][4] = 5; D.pair[4][1] = 6;
+
+  memset(&X, 0, sizeof X);
+  const double kT = (P.temperature + 273.15) * 1.98717;
+  X.kT = kT;
+  auto bw = [kT](double e) { return exp(-e * 10.0 / kT); };
+  auto bws = [kT](double e) { return exp(smooth_term(-e) * 10.0 / kT); };
+  for (int a = 0; a < 8; a++)
+    for (int b = 0; b < 8; b++) X.stack[a][b] = bw(P.stack[a][b]);
+  for (int i = 0; i <= 30; i++) {
+    X.bulge[i] = bw(P.bulge[i]);
+    X.internal_loop[i] = bw(P.internal_loop[i]);
+    X.ninio[i] = bw(P.max_ninio < i * P.ninio ? P.max_ninio : i * P.ninio);
+  }
+  for (int s = 0; s <= SF_MAX_W + 1; s++)
+    X.hp_init[s] = (s <= 30) ? bw(P.hairpin[s]) : bw(P.hairpin[30]) * exp(-(P.lxc * log(s / 30.)) * 10. / kT);
+  for (int t = 0; t < 8; t++)
+    for (int a = 0; a < 5; a++) {
+      X.dangle5[t][a] = bws(P.dangle5[t][a]);
+      X.dangle3[t][a] = bws(P.dangle3[t][a]);
+      for (int b = 0; b < 5; b++) {
+        X.mismatchI[t][a][b] = bw(P.mismatchI[t][a][b]);
+        X.mismatchH[t][a][b] = bw(P.mismatchH[t][a][b]);
+        X.mismatch1nI[t][a][b] = bw(P.mismatch1nI[t][a][b]);
+        X.mismatch23I[t][a][b] = bw(P.mismatch23I[t][a][b]);
+        X.mismatchM[t][a][b] = bws(P.mismatchM[t][a][b]);
+        X.mismatchExt[t][a][b] = bws(P.mismatchExt[t][a][b]);
+      }
+    }
+  for (int a = 0; a < 8; a++)
+    for (int b = 0; b < 8; b++)
+      for (int c = 0; c < 5; c++)
+        for (int d = 0; d < 5; d++) {
+          X.int11[a][b][c][d] = bw(P.int11[a][b][c][d]);
+          for (int e = 0; e < 5; e++) {
+            X.int21[a][b][c][d][e] = bw(P.int21[a][b][c][d][e]);
+            for (int f = 0; f < 5; f++) X.int22[a][b][c][d][e][f] = bw(P.int22[a][b][c][d][e][f]);
+          }
+        }
+  X.MLbase = bw(P.MLbase);
+  X.MLclosing = bw(P.MLclosing);
+  for (int t = 0; t < 8; t++) X.MLintern[t] = bw(P.MLintern[t]);
+  X.TermAU = bw(P.TerminalAU);
+  for (int k = 0; k < SF_NSPECIAL; k++) {
+    X.tetra[k] = bw(P.tetra_E[k]);
+    X.tri[k] = bw(P.tri_E[k]);
+    X.hexa[k] = bw(P.hexa_E[k]);
+  }
+  X.mlbase_pow[0] = 1.0;
+  for (int k = 1; k <= SF_MAX_W + 1; k++) X.mlbase_pow[k] = X.mlbase_pow[k - 1] * X.MLbase;
+}
+
+int max_resident_blocks() { return g.n_cu * 4; }
+
+// FULL kernel over n items; see sf_mfe_full_kernel for the indexing arguments
+int launch_full(const uint8_t *d_seqs, const int *d_idx, const int *d_count, int n, int row_stride, int mfe_stride,
+                int W, int32_t *d_mfe, char *d_db, hipStream_t st) {
+  if (n <= 0) return SF_OK;
+  int grid = n < max_resident_blocks() ? n : max_resident_blocks();
+  int rc = ensure(g.full_scratch, (size_t)grid * SF_FULL_SCRATCH_INTS(W) * sizeof(int32_t));
+  if (rc) return rc;
+  rc = ensure(g.status, sizeof(int));
+  if (rc) return rc;
+  SF_LAUNCH(sf_mfe_full_kernel, grid, block_threads(W), 0, st, d_seqs, d_idx, d_count, n, row_stride, mfe_stride, W,
+            (const SfDevParams *)g.dP, (int32_t *)g.full_scratch.p, d_mfe, d_db, (int *)g.status.p);
+  HIPCHK(hipGetLastError());
+  return SF_OK;
+}
+
+int launch_pf(const uint8_t *d_seqs, int n, int row_stride, int W, double *d_dG, double *d_mbd, char *d_cen,
+              double *d_cd, hipStream_t st) {
+  if (n <= 0) return SF_OK;
+  int grid = n < max_resident_blocks() ? n : max_resident_blocks();
+  int rc = ensure(g.pf_scratch, (size_t)grid * SF_PF_SCRATCH_DOUBLES(W) * sizeof(double));
+  if (rc) return rc;
+  SF_LAUNCH(sf_pf_kernel, grid, block_threads(W), 0, st, d_seqs, n, row_stride, W, (const SfDevParams *)g.dP,
+            (const SfDevParamsPF *)g.dX, (double *)g.pf_scratch.p, d_dG, d_mbd, d_cen, d_cd);
+  HIPCHK(hipGetLastError());
+  return SF_OK;
+}
+
+// energies of n rows: LDS-resident int16 kernel, then the exact int32 kernel on the rows it flagged
+int launch_mfe(const uint8_t *d_seqs, int n, int W, int32_t *d_out, hipStream_t st) {
+  if (n <= 0) return SF_OK;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  int rc = SF_OK;
+  if (g.force_full || !sf_fast_supported(W)) {
+    HIPCHK(hipEventRecord(e0, st));
+    rc = launch_full(d_seqs, nullptr, nullptr, n, 1, 1, W, d_out, nullptr, st);
+    HIPCHK(hipEventRecord(e1, st));
+  } else {
+    rc = ensure(g.ovf, sizeof(int) * ((size_t)n + 1));
+    if (rc) return rc;
+    int *d_cnt = (int *)g.ovf.p, *d_list = d_cnt + 1;
+    HIPCHK(hipMemsetAsync(d_cnt, 0, sizeof(int), st));
+    int grid = 0;
+    size_t lds = 0, scratch_bytes = 0;
+    sf_fast_geometry(W, g.n_cu, n, &grid, &lds, &scratch_bytes);
+    rc = ensure(g.fast_scratch, scratch_bytes);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(e0, st));
+    SF_LAUNCH(sf_mfe_fast_kernel, grid, SF_FAST_THREADS, lds, st, d_seqs, n, W, (const SfFastParams *)g.dF,
+              (int16_t *)g.fast_scratch.p, d_out, d_cnt, d_list);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(e1, st));
+    rc = launch_full(d_seqs, d_list, d_cnt, n, 1, 1, W, d_out, nullptr, st);
+  }
+  g.ev.push_back({e0, e1});
+  g.prof_launches++;
+  g.prof_folds += n;
+  return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *sf_strerror(int status) {
+  switch (status) {
+    case SF_OK: return "ok";
+    case SF_ERR_NOT_INIT: return "sf_init has not been called";
+    case SF_ERR_NO_PARAMS: return "no energy parameters loaded (sf_params_load)";
+    case SF_ERR_BAD_ARG: return "bad argument";
+    case SF_ERR_BAD_PARAMS: return "parameter blob has the wrong size, magic or version";
+    case SF_ERR_TEMPERATURE: return "temperature differs from the one the parameter blob is valid at";
+    case SF_ERR_HIP: return "HIP runtime error (see sf_last_hip_error)";
+    case SF_ERR_NO_DEVICE: return "no usable GPU device";
+    case SF_ERR_INTERNAL: return "internal error: traceback found no decomposition";
+    default: return "unknown status";
+  }
+}
+const char *sf_last_hip_error(void) { return g.last_hip_error.c_str(); }
+
+int sf_init(int device_ordinal) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return SF_ERR_NO_DEVICE;
+  if (device_ordinal < 0 || device_ordinal >= ndev) return SF_ERR_BAD_ARG;
+  if (g.init) {
+    if (g.dev == device_ordinal) return SF_OK;
+    sf_shutdown();
+  }
+  HIPCHK(hipSetDevice(device_ordinal));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device_ordinal));
+  g.n_cu = prop.multiProcessorCount;
+  char nm[256];
+  snprintf(nm, sizeof nm, "%s (%s), %d CUs", prop.name, prop.gcnArchName, g.n_cu);
+  g.dev_name = nm;
+  g.dev = device_ordinal;
+  HIPCHK(hipStreamCreate(&g.stream));
+  HIPCHK(hipMalloc((void **)&g.dP, sizeof(SfDevParams)));
+  HIPCHK(hipMalloc((void **)&g.dX, sizeof(SfDevParamsPF)));
+  HIPCHK(hipMalloc((void **)&g.dF, sizeof(SfFastParams)));
+  HIPCHK(sf_fast_configure());
+  const char *ff = getenv("SCANFOLD_FORCE_FULL");
+  g.force_full = (ff && ff[0] == '1');
+  g.init = true;
+  g.have_params = false;
+  return SF_OK;
+}
+
+int sf_shutdown(void) {
+  if (!g.init) return SF_OK;
+  hipDeviceSynchronize();
+  DevBuf *bufs[] = {&g.full_scratch, &g.pf_scratch, &g.fast_scratch, &g.seqs, &g.energies, &g.db, &g.cen,
+                    &g.dbl, &g.status, &g.transcript, &g.ovf};
+  for (DevBuf *b : bufs) {
+    if (b->p) hipFree(b->p);
+    b->p = nullptr;
+    b->cap = 0;
+  }
+  for (auto &e : g.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+  g.ev.clear();
+  if (g.dP) hipFree(g.dP);
+  if (g.dX) hipFree(g.dX);
+  if (g.dF) hipFree(g.dF);
+  g.dP = nullptr; g.dX = nullptr; g.dF = nullptr;
+  if (g.stream) hipStreamDestroy(g.stream);
+  g.stream = nullptr;
+  g.init = false;
+  g.have_params = false;
+  return SF_OK;
+}
+
+int sf_device_name(char *buf, size_t n) {
+  if (!g.init) return SF_ERR_NOT_INIT;
+  if (!buf || n == 0) return SF_ERR_BAD_ARG;
+  snprintf(buf, n, "%s", g.dev_name.c_str());
+  return SF_OK;
+}
+
+int sf_params_load(const void *blob, size_t nbytes, double temperature_c) {
+  if (!g.init) return SF_ERR_NOT_INIT;
+  if (!blob || nbytes != sizeof(sf_params_blob)) return SF_ERR_BAD_PARAMS;
+  static sf_params_blob P;
+  memcpy(&P, blob, sizeof P);
+  if (P.magic != SF_PARAMS_MAGIC || P.version != SF_PARAMS_VERSION) return SF_ERR_BAD_PARAMS;
+  if (fabs(P.temperature - temperature_c) > 1e-9) return SF_ERR_TEMPERATURE;
+  static SfDevParams D;
+  static SfDevParamsPF X;
+  static SfFastParams F;
+  build_dev_params(P, D, X);
+  sf_fast_build_params(D, F);
+  HIPCHK(hipStreamSynchronize(g.stream));
+  HIPCHK(hipMemcpy(g.dP, &D, sizeof D, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(g.dX, &X, sizeof X, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(g.dF, &F, sizeof F, hipMemcpyHostToDevice));
+  g.temperature = temperature_c;
+  g.have_params = true;
+  return SF_OK;
+}
+
+int sf_mfe_batch_dev(const uint8_t *d_seqs, int n, int W, int32_t *d_out, void *stream) {
+  int rc = check_ready();
+  if (rc) return rc;
+  if (n < 0 || W < 1 || W > SF_MAX_W || (n > 0 && (!d_seqs || !d_out))) return SF_ERR_BAD_ARG;
+  return launch_mfe(d_seqs, n, W, d_out, stream ? (hipStream_t)stream : g.stream);
+}
+
+int sf_mfe_batch(const uint8_t *seqs, int n, int W, int32_t *out) {
+  int rc = check_ready();
+  if (rc) return rc;
+  if (n < 0 || W < 1 || W > SF_MAX_W || (n > 0 && (!seqs || !out))) return SF_ERR_BAD_ARG;
+  if (n == 0) return SF_OK;
+  if ((rc = ensure(g.seqs, (size_t)n * W))) return rc;
+  if ((rc = ensure(g.energies, (size_t)n * sizeof(int32_t)))) return rc;
+  HIPCHK(hipMemcpyAsync(g.seqs.p, seqs, (size_t)n * W, hipMemcpyHostToDevice, g.stream));
+  if ((rc = launch_mfe((const uint8_t *)g.seqs.p, n, W, (int32_t *)g.energies.p, g.stream))) return rc;
+  HIPCHK(hipMemcpyAsync(out, g.energies.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, g.stream));
+  HIPCHK(hipStreamSynchronize(g.stream));
+  return SF_OK;
+}
+
+int sf_mfe_trace_batch(const uint8_t *seqs, int n, int W, int32_t *mfe_out, char *db_out) {
+  int rc = check_ready();
+  if (rc) return rc;
+  if (n < 0 || W < 1 || W > SF_MAX_W || (n > 0 && (!seqs || !db_out))) return SF_ERR_BAD_ARG;
+  if (n == 0) return SF_OK;
+  if ((rc = ensure(g.seqs, (size_t)n * W))) return rc;
+  if ((rc = ensure(g.energies, (size_t)n * sizeof(int32_t)))) return rc;
+  if ((rc = ensure(g.db, (size_t)n * (W + 1)))) return rc;
+  if ((rc = ensure(g.status, sizeof(int)))) return rc;
+  HIPCHK(hipMemsetAsync(g.status.p, 0, sizeof(int), g.stream));
+  HIPCHK(hipMemcpyAsync(g.seqs.p, seqs, (size_t)n * W, hipMemcpyHostToDevice, g.stream));
+  if ((rc = launch_full((const uint8_t *)g.seqs.p, nullptr, nullptr, n, 1, 1, W, (int32_t *)g.energies.p,
+                        (char *)g.db.p, g.stream)))
+    return rc;
+  int st = 0;
+  if (mfe_out)
+    HIPCHK(hipMemcpyAsync(mfe_out, g.energies.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, g.stream));
+  HIPCHK(hipMemcpyAsync(db_out, g.db.p, (size_t)n * (W + 1), hipMemcpyDeviceToHost, g.stream));
+  HIPCHK(hipMemcpyAsync(&st, g.status.p, sizeof(int), hipMemcpyDeviceToHost, g.stream));
+  HIPCHK(hipStreamSynchronize(g.stream));
+  return st ? SF_ERR_INTERNAL : SF_OK;
+}
+
+int sf_pf_batch(const uint8_t *seqs, int n, int W, double *ens_dG, double *mbd, char *centroid, double *cdist) {
+  int rc = check_ready();
+  if (rc) return rc;
+  if (n < 0 || W < 1 || W > SF_MAX_W || (n > 0 && !seqs)) return SF_ERR_BAD_ARG;
+  if (n == 0) return SF_OK;
+  if ((rc = ensure(g.seqs, (size_t)n * W))) return rc;
+  if ((rc = ensure(g.dbl, (size_t)n * 3 * sizeof(double)))) return rc;
+  if ((rc = ensure(g.cen, (size_t)n * (W + 1)))) return rc;
+  double *d_dG = (double *)g.dbl.p, *d_mbd = d_dG + n, *d_cd = d_mbd + n;
+  HIPCHK(hipMemcpyAsync(g.seqs.p, seqs, (size_t)n * W, hipMemcpyHostToDevice, g.stream));
+  if ((rc = launch_pf((const uint8_t *)g.seqs.p, n, 1, W, d_dG, d_mbd, (char *)g.cen.p, d_cd, g.stream))) return rc;
+  if (ens_dG) HIPCHK(hipMemcpyAsync(ens_dG, d_dG, n * sizeof(double), hipMemcpyDeviceToHost, g.stream));
+  if (mbd) HIPCHK(hipMemcpyAsync(mbd, d_mbd, n * sizeof(double), hipMemcpyDeviceToHost, g.stream));
+  if (cdist) HIPCHK(hipMemcpyAsync(cdist, d_cd, n * sizeof(double), hipMemcpyDeviceToHost, g.stream));
+  if (centroid) HIPCHK(hipMemcpyAsync(centroid, g.cen.p, (size_t)n * (W + 1), hipMemcpyDeviceToHost, g.stream));
+  HIPCHK(hipStreamSynchronize(g.stream));
+  return SF_OK;
+}
+
+static int check_scan_args(int L, int W, int step, int win_begin, int n_win, int r, int kind) {
+  if (L < 1 || W < 1 || W > SF_MAX_W || step < 1 || win_begin < 0 || n_win < 0 || r < 0) return SF_ERR_BAD_ARG;
+  if (kind != SF_SHUFFLE_MONO && kind != SF_SHUFFLE_DI) return SF_ERR_BAD_ARG;
+  if (n_win > 0 && (long long)(win_begin + n_win - 1) * step + W > L) return SF_ERR_BAD_ARG;
+  return SF_OK;
+}
+
+static int launch_shuffle(const uint8_t *d_tr, int L, int W, int step, int win_begin, int n_win, int r, int kind,
+                          uint64_t seed, uint8_t *d_seqs, hipStream_t st) {
+  const long long total = (long long)n_win * (r + 1);
+  if (total <= 0) return SF_OK;
+  const int grid = (int)((total + SF_SHUF_BLOCK - 1) / SF_SHUF_BLOCK);
+  const size_t lds = (((size_t)SF_SHUF_BLOCK * W + 3) & ~(size_t)3) * 2 + SF_SHUF_BLOCK * 25 * sizeof(uint16_t);
+  SF_LAUNCH(sf_shuffle_kernel, grid, SF_SHUF_BLOCK, lds, st, d_tr, L, W, step, win_begin, n_win, r, kind, seed, d_seqs);
+  HIPCHK(hipGetLastError());
+  return SF_OK;
+}
+
+int sf_shuffle_windows(const uint8_t *transcript, int L, int W, int step, int win_begin, int n_win, int r, int kind,
+                       uint64_t seed, uint8_t *seqs_out) {
+  if (!g.init) return SF_ERR_NOT_INIT;
+  int rc = check_scan_args(L, W, step, win_begin, n_win, r, kind);
+  if (rc) return rc;
+  if (!transcript || (n_win > 0 && !seqs_out)) return SF_ERR_BAD_ARG;
+  if (n_win == 0) return SF_OK;
+  const size_t nb = (size_t)n_win * (r + 1) * W;
+  if ((rc = ensure(g.transcript, (size_t)L))) return rc;
+  if ((rc = ensure(g.seqs, nb))) return rc;
+  HIPCHK(hipMemcpyAsync(g.transcript.p, transcript, (size_t)L, hipMemcpyHostToDevice, g.stream));
+  if ((rc = launch_shuffle((const uint8_t *)g.transcript.p, L, W, step, win_begin, n_win, r, kind, seed,
+                           (uint8_t *)g.seqs.p, g.stream)))
+    return rc;
+  HIPCHK(hipMemcpyAsync(seqs_out, g.seqs.p, nb, hipMemcpyDeviceToHost, g.stream));
+  HIPCHK(hipStreamSynchronize(g.stream));
+  return SF_OK;
+}
+
+int sf_scan_dev(const uint8_t *d_tr, int L, int W, int step, int win_begin, int n_win, int r, int kind, uint64_t seed,
+                unsigned flags, int32_t *d_energies, char *d_structure, char *d_centroid, double *d_ens_div,
+                double *d_ens_dG, void *stream) {
+  int rc = check_ready();
+  if (rc) return rc;
+  if ((rc = check_scan_args(L, W, step, win_begin, n_win, r, kind))) return rc;
+  if (!d_tr || (n_win > 0 && !d_energies)) return SF_ERR_BAD_ARG;
+  if (n_win == 0) return SF_OK;
+  hipStream_t st = stream ? (hipStream_t)stream : g.stream;
+  // windows are processed in chunks so the materialised shuffles stay below ~1 GiB
+  const size_t row_bytes = (size_t)(r + 1) * W;
+  int chunk = (int)(((size_t)1 << 30) / row_bytes);
+  if (chunk < 1) chunk = 1;
+  if (chunk > n_win) chunk = n_win;
+  if ((rc = ensure(g.seqs, (size_t)chunk * row_bytes))) return rc;
+  uint8_t *d_seqs = (uint8_t *)g.seqs.p;
+  for (int w0 = 0; w0 < n_win; w0 += chunk) {
+    const int nw = (n_win - w0 < chunk) ? n_win - w0 : chunk;
+    if ((rc = launch_shuffle(d_tr, L, W, step, win_begin + w0, nw, r, kind, seed, d_seqs, st))) return rc;
+    if ((rc = launch_mfe(d_seqs, nw * (r + 1), W, d_energies + (size_t)w0 * (r + 1), st))) return rc;
+    if (!(flags & SF_SCAN_NO_TRACE) && d_structure) {
+      // native rows only (row stride r+1); the energy is NOT rewritten: structure string only
+      if ((rc = launch_full(d_seqs, nullptr, nullptr, nw, r + 1, 0, W, nullptr, d_structure + (size_t)w0 * (W + 1), st)))
+        return rc;
+    }
+    if (!(flags & SF_SCAN_NO_PF)) {
+      if ((rc = launch_pf(d_seqs, nw, r + 1, W, d_ens_dG ? d_ens_dG + w0 : nullptr, d_ens_div ? d_ens_div + w0 : nullptr,
+                          d_centroid ? d_centroid + (size_t)w0 * (W + 1) : nullptr, nullptr, st)))
+        return rc;
+    }
+  }
+  return SF_OK;
+}
+
+int sf_scan(const uint8_t *transcript, int L, int W, int step, int win_begin, int n_win, int r, int kind, uint64_t seed,
+            unsigned flags, int32_t *energies, char *structure, char *centroid, double *ens_div, double *ens_dG) {
+  int rc = check_ready();
+  if (rc) return rc;
+  if ((rc = check_scan_args(L, W, step, win_begin, n_win, r, kind))) return rc;
+  if (!transcript || (n_win > 0 && !energies)) return SF_ERR_BAD_ARG;
+  if (n_win == 0) return SF_OK;
+  const size_t ne = (size_t)n_win * (r + 1);
+  if ((rc = ensure(g.transcript, (size_t)L))) return rc;
+  if ((rc = ensure(g.energies, ne * sizeof(int32_t)))) return rc;
+  if ((rc = ensure(g.db, (size_t)n_win * (W + 1)))) return rc;
+  if ((rc = ensure(g.cen, (size_t)n_win * (W + 1)))) return rc;
+  if ((rc = ensure(g.dbl, (size_t)n_win * 2 * sizeof(double)))) return rc;
+  if ((rc = ensure(g.status, sizeof(int)))) return rc;
+  double *d_div = (double *)g.dbl.p, *d_dG = d_div + n_win;
+  HIPCHK(hipMemsetAsync(g.status.p, 0, sizeof(int), g.stream));
+  HIPCHK(hipMemcpyAsync(g.transcript.p, transcript, (size_t)L, hipMemcpyHostToDevice, g.stream));
+  rc = sf_scan_dev((const uint8_t *)g.transcript.p, L, W, step, win_begin, n_win, r, kind, seed, flags,
+                   (int32_t *)g.energies.p, structure ? (char *)g.db.p : nullptr, centroid ? (char *)g.cen.p : nullptr,
+                   ens_div ? d_div : nullptr, ens_dG ? d_dG : nullptr, g.stream);
+  if (rc) return rc;
+  int st = 0;
+  HIPCHK(hipMemcpyAsync(energies, g.energies.p, ne * sizeof(int32_t), hipMemcpyDeviceToHost, g.stream));
+  if (structure && !(flags & SF_SCAN_NO_TRACE))
+    HIPCHK(hipMemcpyAsync(structure, g.db.p, (size_t)n_win * (W + 1), hipMemcpyDeviceToHost, g.stream));
+  if (!(flags & SF_SCAN_NO_PF)) {
+    if (centroid) HIPCHK(hipMemcpyAsync(centroid, g.cen.p, (size_t)n_win * (W + 1), hipMemcpyDeviceToHost, g.stream));
+    if (ens_div) HIPCHK(hipMemcpyAsync(ens_div, d_div, n_win * sizeof(double), hipMemcpyDeviceToHost, g.stream));
+    if (ens_dG) HIPCHK(hipMemcpyAsync(ens_dG, d_dG, n_win * sizeof(double), hipMemcpyDeviceToHost, g.stream));
+  }
+  HIPCHK(hipMemcpyAsync(&st, g.status.p, sizeof(int), hipMemcpyDeviceToHost, g.stream));
+  HIPCHK(hipStreamSynchronize(g.stream));
+  return st ? SF_ERR_INTERNAL : SF_OK;
+}
+
+int sf_prof_reset(void) {
+  if (!g.init) return SF_ERR_NOT_INIT;
+  HIPCHK(hipDeviceSynchronize());
+  for (auto &e : g.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+  g.ev.clear();
+  g.prof_ms = 0.0;
+  g.prof_launches = 0;
+  g.prof_folds = 0;
+  return SF_OK;
+}
+
+int sf_prof_get(double *ms, int64_t *launches, int64_t *folds) {
+  if (!g.init) return SF_ERR_NOT_INIT;
+  HIPCHK(hipDeviceSynchronize());
+  for (auto &e : g.ev) {
+    float t = 0.f;
+    HIPCHK(hipEventElapsedTime(&t, e.first, e.second));
+    g.prof_ms += t;
+    hipEventDestroy(e.first);
+    hipEventDestroy(e.second);
+  }
+  g.ev.clear();
+  if (ms) *ms = g.prof_ms;
+  if (launches) *launches = g.prof_launches;
+  if (folds) *folds = g.prof_folds;
+  return SF_OK;
+}
+
+}  // extern "C"

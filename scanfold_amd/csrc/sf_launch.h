@@ -1,0 +1,11 @@
+// sf_launch.h — kernel-launch and dynamic-LDS spelling used by every kernel file.
+// The product build is plain HIP for gfx950.  tests/emul/ compiles the same sources with g++ against a
+// fiber-based stand-in (TEST ONLY, see tests/emul/hip_emul.h) by pre-including that header, which
+// defines SF_EMUL and its own SF_LAUNCH / SF_DYN_SMEM.
+#pragma once
+#ifndef SF_EMUL
+#include <hip/hip_runtime.h>
+#define SF_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
+#define SF_LAUNCH(kern, grid, block, shmem, stream, ...) \
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(block), shmem, stream, __VA_ARGS__)
+#endif

@@ -42,6 +42,7 @@ struct Ctx {
   double prof_ms = 0.0;
   int64_t prof_launches = 0, prof_folds = 0;
   int force_full = 0;
+  int fast_ok = 0;
 } g;
 
 #define HIPCHK(call)                                                              \
@@ -189,7 +190,7 @@ int launch_mfe(const uint8_t *d_seqs, int n, int W, int32_t *d_out, hipStream_t 
   HIPCHK(hipEventCreate(&e0));
   HIPCHK(hipEventCreate(&e1));
   int rc = SF_OK;
-  if (g.force_full || !sf_fast_supported(W)) {
+  if (g.force_full || !g.fast_ok || !sf_fast_w_supported(W)) {
     HIPCHK(hipEventRecord(e0, st));
     rc = launch_full(d_seqs, nullptr, nullptr, n, 1, 1, W, d_out, nullptr, st);
     HIPCHK(hipEventRecord(e1, st));
@@ -198,16 +199,17 @@ int launch_mfe(const uint8_t *d_seqs, int n, int W, int32_t *d_out, hipStream_t 
     if (rc) return rc;
     int *d_cnt = (int *)g.ovf.p, *d_list = d_cnt + 1;
     HIPCHK(hipMemsetAsync(d_cnt, 0, sizeof(int), st));
-    int grid = 0;
+    int grid = 0, threads = 0;
     size_t lds = 0, scratch_bytes = 0;
-    sf_fast_geometry(W, g.n_cu, n, &grid, &lds, &scratch_bytes);
+    sf_fast_geometry(W, g.n_cu, n, &grid, &threads, &lds, &scratch_bytes);
     rc = ensure(g.fast_scratch, scratch_bytes);
     if (rc) return rc;
     HIPCHK(hipEventRecord(e0, st));
-    SF_LAUNCH(sf_mfe_fast_kernel, grid, SF_FAST_THREADS, lds, st, d_seqs, n, W, (const SfFastParams *)g.dF,
-              (int16_t *)g.fast_scratch.p, d_out, d_cnt, d_list);
+    sf_fast_launch(grid, threads, lds, st, d_seqs, n, W, (const SfDevParams *)g.dP, (const SfFastParams *)g.dF,
+                   (int16_t *)g.fast_scratch.p, d_out, d_cnt, d_list);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(e1, st));
+    // folds that left the int16 range are redone exactly
     rc = launch_full(d_seqs, d_list, d_cnt, n, 1, 1, W, d_out, nullptr, st);
   }
   g.ev.push_back({e0, e1});
@@ -249,7 +251,7 @@ int sf_init(int device_ordinal) {
   HIPCHK(hipGetDeviceProperties(&prop, device_ordinal));
   g.n_cu = prop.multiProcessorCount;
   char nm[256];
-  snprintf(nm, sizeof nm, "%s (%s), %d CUs", prop.name, prop.gcnArchName, g.n_cu);
+  snprintf(nm, sizeof nm, "%s (%s), %d CUs", prop.name[0] ? prop.name : "AMD GPU", prop.gcnArchName, g.n_cu);
   g.dev_name = nm;
   g.dev = device_ordinal;
   HIPCHK(hipStreamCreate(&g.stream));
@@ -306,6 +308,7 @@ int sf_params_load(const void *blob, size_t nbytes, double temperature_c) {
   static SfFastParams F;
   build_dev_params(P, D, X);
   sf_fast_build_params(D, F);
+  g.fast_ok = F.fast_ok;
   HIPCHK(hipStreamSynchronize(g.stream));
   HIPCHK(hipMemcpy(g.dP, &D, sizeof D, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(g.dX, &X, sizeof X, hipMemcpyHostToDevice));

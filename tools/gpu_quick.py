@@ -25,7 +25,7 @@ for W, n in ((30, 64), (120, 512), (200, 64)):
         o = oracle.pf(bytes(arr[k]).decode())
         ok &= abs(o['dG'] - r['dG'][k]) < 1e-8 and o['centroid'] == r['centroid'][k] and abs(o['mean_bp_dist'] - r['mean_bp_dist'][k]) < 1e-8
     print("  pf parity", ok, "t %.3fs" % (t1 - t0), flush=True)
-for n in (4096, 32768):
+for n in (4096, 32768, 262144):
     arr = np.frombuffer(b"ACGU", dtype=np.uint8)[rng.integers(0, 4, (n, 120))]
     eng.mfe_batch(arr[:256])
     eng.prof_reset()

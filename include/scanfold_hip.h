@@ -99,6 +99,10 @@ int sf_scan_dev(const uint8_t *d_transcript, int L, int W, int step, int win_beg
                 int shuffle_kind, uint64_t seed, unsigned flags, int32_t *d_energies, char *d_structure,
                 char *d_centroid, double *d_ens_div, double *d_ens_dG, void *stream);
 
+/* Diagnostics: 0 = automatic (LDS int16 kernel with int32 fallback), 1 = always the int32 kernel.
+ * Results are identical in both modes; tests use it to cross-check the two kernels. */
+int sf_set_kernel_mode(int mode);
+
 /* Measurement support for bench.py: HIP-event time (ms) and launch count of the dominant kernel
  * (the batched MFE fill) accumulated since the last reset, measured on the stream it was launched on. */
 int sf_prof_reset(void);

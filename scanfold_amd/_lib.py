@@ -42,6 +42,7 @@ _EXPORTS = {
                                    ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint, ctypes.c_void_p,
                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                    ctypes.c_void_p]),
+    "sf_set_kernel_mode": (ctypes.c_int, [ctypes.c_int]),
     "sf_prof_reset": (ctypes.c_int, []),
     "sf_prof_get": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64),
                                    ctypes.POINTER(ctypes.c_int64)]),
@@ -164,6 +165,18 @@ class Engine:
                                      div.ctypes.data, dG.ctypes.data))
         return dict(energies=en, structure=[bytes(x[:W]).decode() for x in db],
                     centroid=[bytes(x[:W]).decode() for x in cen], ens_div=div, ens_dG=dG)
+
+    # -- device-buffer entry points (pointers are ints, e.g. torch.Tensor.data_ptr(); stream 0 = library stream) --
+    def mfe_batch_dev(self, d_seqs, n, W, d_out, stream=0):
+        self._check(self.lib.sf_mfe_batch_dev(d_seqs, n, W, d_out, stream))
+
+    def scan_dev(self, d_transcript, L, W, step, win_begin, n_win, r, kind, seed, flags, d_energies, d_structure,
+                 d_centroid, d_ens_div, d_ens_dG, stream=0):
+        self._check(self.lib.sf_scan_dev(d_transcript, L, W, step, win_begin, n_win, r, kind, ctypes.c_uint64(seed),
+                                         flags, d_energies, d_structure, d_centroid, d_ens_div, d_ens_dG, stream))
+
+    def set_kernel_mode(self, mode):
+        self._check(self.lib.sf_set_kernel_mode(int(mode)))
 
     def prof_reset(self):
         self._check(self.lib.sf_prof_reset())

@@ -487,6 +487,13 @@ int sf_scan(const uint8_t *transcript, int L, int W, int step, int win_begin, in
   return st ? SF_ERR_INTERNAL : SF_OK;
 }
 
+int sf_set_kernel_mode(int mode) {
+  if (!g.init) return SF_ERR_NOT_INIT;
+  if (mode != 0 && mode != 1) return SF_ERR_BAD_ARG;
+  g.force_full = mode;
+  return SF_OK;
+}
+
 int sf_prof_reset(void) {
   if (!g.init) return SF_ERR_NOT_INIT;
   HIPCHK(hipDeviceSynchronize());

@@ -1,0 +1,97 @@
+"""Multi-GPU sharding of the window scan: one process per GPU, windows split by contiguous range, ONE gather.
+
+The reference has no distributed layer (its only parallelism is a 12-process pool on one host,
+ScanFold-Scan.py:73-77).  Windows are independent and the per-window reduction (z/p over its r+1 energies,
+ScanFold-Scan.py:426-433) stays inside a shard when sharding is by window, so the only exchange is a gather of
+fixed-size per-window records at the end.  torch.distributed is used for exactly that:
+backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.
+
+Record layout (bytes, per window): int32 energies[r+1] | char structure[W+1] | char centroid[W+1] |
+pad to 8 | float64 ens_div | float64 ens_dG.
+"""
+import numpy as np
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous [lo, hi) of rank's items; every rank but the last gets ceil(n/world)."""
+    per = -(-n_items // world) if world > 0 else n_items
+    lo = min(n_items, rank * per)
+    hi = min(n_items, lo + per)
+    return lo, hi
+
+
+def shard_size(n_items, world):
+    return -(-n_items // world)
+
+
+def record_layout(W, r):
+    e = 4 * (r + 1)
+    s = W + 1
+    txt_end = e + 2 * s
+    dbl = (txt_end + 7) & ~7
+    return dict(energies=(0, e), structure=(e, e + s), centroid=(e + s, txt_end), ens_div=(dbl, dbl + 8),
+                ens_dG=(dbl + 8, dbl + 16), size=dbl + 16)
+
+
+def pack_records(xp, W, r, energies, structure, centroid, ens_div, ens_dG, n_pad):
+    """xp is `torch` or `numpy`; inputs are arrays/tensors of n rows; returns uint8 [n_pad, size]."""
+    lay = record_layout(W, r)
+    n = energies.shape[0]
+    if xp.__name__ == "torch":
+        rec = xp.zeros((n_pad, lay["size"]), dtype=xp.uint8, device=energies.device)
+        as_u8 = lambda t: t.contiguous().view(xp.uint8).reshape(n, -1)
+    else:
+        rec = xp.zeros((n_pad, lay["size"]), dtype=xp.uint8)
+        as_u8 = lambda t: xp.ascontiguousarray(t).view(xp.uint8).reshape(n, -1)
+    for key, arr in (("energies", energies), ("structure", structure), ("centroid", centroid),
+                     ("ens_div", ens_div), ("ens_dG", ens_dG)):
+        lo, hi = lay[key]
+        rec[:n, lo:hi] = as_u8(arr)
+    return rec
+
+
+def unpack_records(rec, W, r, n):
+    """uint8 numpy [>=n, size] -> dict of numpy arrays for the first n windows."""
+    lay = record_layout(W, r)
+    rec = np.ascontiguousarray(rec[:n])
+    get = lambda key: np.ascontiguousarray(rec[:, lay[key][0]:lay[key][1]])
+    return dict(energies=get("energies").view(np.int32).reshape(n, r + 1),
+                structure=get("structure"), centroid=get("centroid"),
+                ens_div=get("ens_div").view(np.float64).reshape(n),
+                ens_dG=get("ens_dG").view(np.float64).reshape(n))
+
+
+def gather_records(local_rec, world):
+    """One all-gather of the equal-sized shards; returns the [world*n_pad, size] tensor on every rank."""
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return local_rec
+    out = torch.empty((world * local_rec.shape[0], local_rec.shape[1]), dtype=torch.uint8, device=local_rec.device)
+    dist.all_gather_into_tensor(out, local_rec.contiguous())
+    return out
+
+
+def merge_shards(gathered, n_items, world, W, r):
+    """Drop each shard's padding and restore window order -> dict of numpy arrays for all n_items windows."""
+    per = shard_size(n_items, world)
+    g = gathered.cpu().numpy() if hasattr(gathered, "cpu") else np.asarray(gathered)
+    parts = []
+    for rank in range(world):
+        lo, hi = shard_range(n_items, rank, world)
+        parts.append(g[rank * per: rank * per + (hi - lo)])
+    rec = np.concatenate(parts, axis=0) if parts else g[:0]
+    return unpack_records(rec, W, r, n_items)
+
+
+def scan_sharded(produce, n_win, W, r, rank, world, xp):
+    """Run `produce(lo, hi)` -> (energies, structure, centroid, ens_div, ens_dG) on this rank's windows,
+    gather every shard, and return the merged dict (same on all ranks)."""
+    lo, hi = shard_range(n_win, rank, world)
+    e, s, c, d, g = produce(lo, hi)
+    rec = pack_records(xp, W, r, e, s, c, d, g, shard_size(n_win, world))
+    if xp.__name__ == "torch":
+        gathered = gather_records(rec, world)
+    else:
+        gathered = rec  # numpy path is single-process only
+    return merge_shards(gathered, n_win, world, W, r)

@@ -1,0 +1,73 @@
+"""The N>1 path on CPU: window sharding + the single gather, world_size 2 over gloo."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+
+from scanfold_amd import dist as sdist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_ranges_cover_everything_once():
+    for n in (0, 1, 7, 23, 989, 29881):
+        for world in (1, 2, 4, 8):
+            spans = [sdist.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(hi - lo for lo, hi in spans) <= sdist.shard_size(n, world)
+
+
+def fake_records(lo, hi, W, r):
+    idx = np.arange(lo, hi)
+    e = (idx[:, None] * 1000 + np.arange(r + 1)[None, :]).astype(np.int32) * -1
+    s = np.zeros((hi - lo, W + 1), dtype=np.uint8); s[:, :W] = ord("."); s[:, 0] = 40 + (idx % 50)
+    c = np.zeros((hi - lo, W + 1), dtype=np.uint8); c[:, :W] = ord("."); c[:, 1] = 41 + (idx % 50)
+    return e, s, c, idx * 0.5, idx * -0.25
+
+
+def test_pack_unpack_roundtrip_numpy():
+    W, r, n = 37, 10, 13
+    e, s, c, d, g = fake_records(0, n, W, r)
+    rec = sdist.pack_records(np, W, r, e, s, c, d, g, n + 3)
+    assert rec.shape == (n + 3, sdist.record_layout(W, r)["size"]) and sdist.record_layout(W, r)["size"] % 8 == 0
+    out = sdist.unpack_records(rec, W, r, n)
+    assert (out["energies"] == e).all() and (out["structure"] == s).all() and (out["centroid"] == c).all()
+    assert (out["ens_div"] == d).all() and (out["ens_dG"] == g).all()
+
+
+WORKER = textwrap.dedent("""
+    import os, sys, json
+    sys.path.insert(0, %(root)r)
+    sys.path.insert(0, os.path.join(%(root)r, "tests"))
+    import numpy as np, torch, torch.distributed as dist
+    from scanfold_amd import dist as sdist
+    from test_dist_gloo import fake_records
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    W, r, n_win = 24, 5, 11   # 11 windows over 2 ranks: ragged last shard
+    def produce(lo, hi):
+        return tuple(torch.from_numpy(np.ascontiguousarray(a)) for a in fake_records(lo, hi, W, r))
+    out = sdist.scan_sharded(produce, n_win, W, r, rank, world, torch)
+    e, s, c, d, g = fake_records(0, n_win, W, r)
+    ok = (out["energies"] == e).all() and (out["structure"] == s).all() and (out["centroid"] == c).all() \\
+        and (out["ens_div"] == d).all() and (out["ens_dG"] == g).all()
+    print("RANK%%d_OK=%%s" %% (rank, bool(ok)))
+    dist.destroy_process_group()
+""")
+
+
+def test_two_rank_gather_over_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT})
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                         capture_output=True, text=True, timeout=300, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "RANK0_OK=True" in out.stdout and "RANK1_OK=True" in out.stdout, out.stdout + out.stderr[-1000:]

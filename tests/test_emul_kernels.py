@@ -1,0 +1,118 @@
+"""Kernel LOGIC on the CPU: the kernel sources compiled against tests/emul/hip_emul.h vs the oracle.
+
+This is test infrastructure (the product never loads the emulation build); it lets the no-GPU suite catch
+indexing mistakes in the HIP sources before a GPU run, and it is the build the sanitizers run on.
+The real parity tests are tests/test_gpu_parity.py (-m gpu)."""
+from collections import Counter
+
+import numpy as np
+import pytest
+
+from scanfold_amd import params
+from conftest import random_seqs
+
+
+@pytest.fixture(scope="module")
+def emul():
+    from emul_engine import emul_engine
+    return emul_engine()
+
+
+def ascii_rows(codes):
+    return np.frombuffer(b"NACGU", dtype=np.uint8)[codes]
+
+
+def test_fast_and_full_mfe_kernels_match_oracle(emul, oracle):
+    emul.load_params(params.default_params())
+    rng = np.random.default_rng(0)
+    for W, n in ((8, 8), (13, 10), (37, 8), (64, 6), (120, 4)):
+        arr = random_seqs(rng, n, W)
+        ref = oracle.mfe_batch(arr)
+        emul.set_kernel_mode(0)
+        assert (emul.mfe_batch(arr) == ref).all(), W
+        emul.set_kernel_mode(1)
+        assert (emul.mfe_batch(arr) == ref).all(), W
+        emul.set_kernel_mode(0)
+
+
+def test_int16_overflow_falls_back_to_exact_kernel(emul, oracle):
+    W = 100
+    arr = np.zeros((2, W), dtype=np.uint8)
+    arr[0, :W // 2] = ord("G"); arr[0, W // 2:] = ord("C")
+    arr[1] = np.frombuffer(("GC" * W)[:W].encode(), dtype=np.uint8)
+    ref = oracle.mfe_batch(arr)
+    assert ref.min() < -12000
+    assert (emul.mfe_batch(arr) == ref).all()
+
+
+def test_traceback_and_partition_function(emul, oracle):
+    rng = np.random.default_rng(1)
+    for W in (30, 90):
+        arr = random_seqs(rng, 4, W)
+        e, db = emul.mfe_trace_batch(arr)
+        r = emul.pf_batch(arr)
+        for k in range(len(arr)):
+            s = bytes(arr[k]).decode()
+            odb, oe = oracle.mfe(s)
+            o = oracle.pf(s)
+            assert (db[k], e[k]) == (odb, oe)
+            assert abs(o["dG"] - r["dG"][k]) < 1e-9 and o["centroid"] == r["centroid"][k]
+            assert abs(o["mean_bp_dist"] - r["mean_bp_dist"][k]) < 1e-9
+            assert abs(o["centroid_dist"] - r["centroid_dist"][k]) < 1e-9
+
+
+def test_randomised_tables_catch_index_order(emul):
+    from oracle import oracle as orc
+    rng = np.random.default_rng(2)
+    p = params.random_params(7)
+    orc.set_params(p)
+    emul.load_params(p)
+    arr = random_seqs(rng, 6, 60)
+    assert (emul.mfe_batch(arr) == orc.mfe_batch(arr)).all()
+    e, db = emul.mfe_trace_batch(arr)
+    assert db == [orc.mfe(bytes(r).decode())[0] for r in arr]
+    emul.load_params(params.default_params())
+
+
+def test_n_and_lowercase_and_t(emul, oracle):
+    seqs = ["GGGGAAAANCCCCNNNNNNN", "ggggaaaaccccaaaaaaaa", "GGGGTTTTCCCCAAAAAAAA", "NNNNNNNNNNNNNNNNNNNN"]
+    assert list(emul.mfe_batch(seqs)) == [oracle.mfe(s)[1] for s in seqs]
+
+
+def test_device_shuffles_and_scan(emul, oracle):
+    rng = np.random.default_rng(3)
+    tr = "".join("ACGU"[k] for k in rng.integers(0, 4, 260))
+    W, step, r = 50, 30, 6
+    nwin = (len(tr) - W) // step + 1
+    for kind in (0, 1):
+        rows = ascii_rows(emul.shuffle_windows(tr, W, step, 0, nwin, r, kind, 99))
+        for w in range(nwin):
+            nat = bytes(rows[w * (r + 1)]).decode()
+            assert nat == tr[w * step:w * step + W]
+            for k in range(1, r + 1):
+                s = bytes(rows[w * (r + 1) + k]).decode()
+                if kind == 0:
+                    assert Counter(s) == Counter(nat)
+                else:
+                    assert s[0] == nat[0] and s[-1] == nat[-1] and Counter(zip(s, s[1:])) == Counter(zip(nat, nat[1:]))
+        # a window's shuffles do not depend on batching
+        part = emul.shuffle_windows(tr, W, step, 2, 3, r, kind, 99)
+        assert (ascii_rows(part) == rows[2 * (r + 1):5 * (r + 1)]).all()
+    res = emul.scan(tr, W, step, 0, nwin, r, 1, 99)
+    rows = ascii_rows(emul.shuffle_windows(tr, W, step, 0, nwin, r, 1, 99))
+    assert (res["energies"].reshape(-1) == oracle.mfe_batch(rows)).all()
+    for w in range(nwin):
+        s = tr[w * step:w * step + W]
+        assert oracle.mfe(s)[0] == res["structure"][w]
+        assert oracle.pf(s)["centroid"] == res["centroid"][w]
+
+
+def test_bad_arguments_return_status(emul):
+    from scanfold_amd._lib import ScanFoldHipError
+    with pytest.raises(ScanFoldHipError):
+        emul.mfe_batch(np.zeros((1, 500), dtype=np.uint8))  # W > SF_MAX_W
+    with pytest.raises(ScanFoldHipError):
+        emul.scan("ACGU" * 10, 30, 1, 0, 50, 2, 1, 0)  # windows run past the transcript
+    with pytest.raises(ScanFoldHipError):
+        emul.scan("ACGU" * 10, 30, 1, 0, 2, 2, 7, 0)  # unknown shuffle kind
+    assert len(emul.mfe_batch(np.zeros((0, 30), dtype=np.uint8))) == 0

@@ -1,0 +1,288 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the oracle on the same inputs.
+
+Bars: integer energies (dcal/mol), structure and centroid strings, TSV bytes — bit-exact;
+partition-function scalars (FP64 on both sides, different summation order) — |delta| < 1e-8.
+Nothing here reads /root/reference (absent on the GPU box)."""
+import json
+import os
+from collections import Counter
+
+import numpy as np
+import pytest
+
+from scanfold_amd import _lib, params
+from scanfold_amd import scan as scanmod
+from conftest import random_seqs
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PF_TOL = 1e-8
+
+
+def ascii_rows(codes):
+    return np.frombuffer(b"NACGU", dtype=np.uint8)[codes]
+
+
+def synth_transcript(L, seed):
+    return "".join("ACGU"[k] for k in np.random.default_rng(seed).integers(0, 4, L))
+
+
+def test_engine_reports_a_gfx950_device(gpu_engine):
+    assert "gfx950" in gpu_engine.device_name()
+
+
+def test_committed_vectors(gpu_engine):
+    items = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_vectors.json")))["items"]
+    for it in items:
+        e, db = gpu_engine.mfe_trace_batch([it["seq"]])
+        assert (int(e[0]), db[0]) == (it["mfe_dcal"], it["structure"]), it["seq"]
+        assert int(gpu_engine.mfe_batch([it["seq"]])[0]) == it["mfe_dcal"]
+        r = gpu_engine.pf_batch([it["seq"]])
+        assert r["centroid"][0] == it["centroid"]
+        assert abs(r["dG"][0] - it["ens_dG"]) < PF_TOL and abs(r["mean_bp_dist"][0] - it["mean_bp_dist"]) < PF_TOL
+        assert abs(r["centroid_dist"][0] - it["centroid_dist"]) < PF_TOL
+
+
+@pytest.mark.parametrize("W,n", [(8, 64), (9, 64), (30, 512), (77, 512), (120, 4096), (128, 256), (129, 256),
+                                  (200, 512), (256, 64), (300, 16), (400, 4), (5, 8)])
+def test_mfe_energy_parity_both_kernels(gpu_engine, oracle, W, n):
+    arr = random_seqs(np.random.default_rng(W * 1000 + n), n, W)
+    ref = oracle.mfe_batch(arr)
+    gpu_engine.set_kernel_mode(0)
+    fast = gpu_engine.mfe_batch(arr)
+    gpu_engine.set_kernel_mode(1)
+    full = gpu_engine.mfe_batch(arr[: min(n, 512)])
+    gpu_engine.set_kernel_mode(0)
+    assert (fast == ref).all(), int((fast != ref).sum())
+    assert (full == ref[: len(full)]).all()
+
+
+def test_biased_compositions_and_int16_overflow_fallback(gpu_engine, oracle):
+    rng = np.random.default_rng(5)
+    W = 120
+    gc = np.frombuffer(b"GC", dtype=np.uint8)[rng.integers(0, 2, (64, W))]
+    au = np.frombuffer(b"AU", dtype=np.uint8)[rng.integers(0, 2, (64, W))]
+    helix = np.zeros((2, W), dtype=np.uint8)
+    helix[0, :W // 2] = ord("G"); helix[0, W // 2:] = ord("C")
+    helix[1] = np.frombuffer(("GC" * W)[:W].encode(), dtype=np.uint8)
+    arr = np.concatenate([gc, au, helix])
+    ref = oracle.mfe_batch(arr)
+    assert ref.min() < -12000  # the helix rows leave the int16-safe range and must come back exact
+    assert (gpu_engine.mfe_batch(arr) == ref).all()
+
+
+def test_traceback_and_partition_function_parity(gpu_engine, oracle):
+    for W, n in ((30, 64), (120, 128), (200, 16)):
+        arr = random_seqs(np.random.default_rng(W), n, W)
+        e, db = gpu_engine.mfe_trace_batch(arr)
+        r = gpu_engine.pf_batch(arr)
+        for k in range(n):
+            s = bytes(arr[k]).decode()
+            odb, oe = oracle.mfe(s)
+            assert (db[k], int(e[k])) == (odb, oe)
+            assert oracle.eval_structure(s, db[k]) == oe
+            o = oracle.pf(s)
+            assert o["centroid"] == r["centroid"][k]
+            assert abs(o["dG"] - r["dG"][k]) < PF_TOL
+            assert abs(o["mean_bp_dist"] - r["mean_bp_dist"][k]) < PF_TOL
+            assert abs(o["centroid_dist"] - r["centroid_dist"][k]) < PF_TOL
+
+
+def test_randomised_parameter_tables(gpu_engine):
+    from oracle import oracle as orc
+    try:
+        for seed in (0, 1):
+            p = params.random_params(seed)
+            if seed:
+                p.rec["MLclosing"] = -150
+            orc.set_params(p)
+            gpu_engine.load_params(p)
+            arr = random_seqs(np.random.default_rng(seed), 256, 90)
+            assert (gpu_engine.mfe_batch(arr) == orc.mfe_batch(arr)).all()
+            e, db = gpu_engine.mfe_trace_batch(arr[:32])
+            assert db == [orc.mfe(bytes(r).decode())[0] for r in arr[:32]]
+            r = gpu_engine.pf_batch(arr[:8])
+            for k in range(8):
+                assert abs(orc.pf(bytes(arr[k]).decode())["dG"] - r["dG"][k]) < PF_TOL
+    finally:
+        gpu_engine.load_params(params.default_params())
+
+
+def test_n_lowercase_t_and_codes_inputs(gpu_engine, oracle):
+    seqs = ["GGGGAAAANCCCCNNNNNNN", "ggggaaaaccccaaaaaaaa", "GGGGTTTTCCCCAAAAAAAA", "NNNNNNNNNNNNNNNNNNNN"]
+    ref = [oracle.mfe(s)[1] for s in seqs]
+    assert list(gpu_engine.mfe_batch(seqs)) == ref
+    codes = np.array([[{"A": 1, "C": 2, "G": 3, "U": 4, "T": 4}.get(ch.upper(), 0) for ch in s] for s in seqs],
+                     dtype=np.uint8)
+    assert list(gpu_engine.mfe_batch(codes)) == ref
+
+
+def test_device_shuffles_preserve_the_reference_invariants(gpu_engine):
+    tr = synth_transcript(3000, 8)
+    W, step, r = 120, 60, 20
+    nwin = (len(tr) - W) // step + 1
+    for kind in (_lib.SHUFFLE_MONO, _lib.SHUFFLE_DI):
+        rows = ascii_rows(gpu_engine.shuffle_windows(tr, W, step, 0, nwin, r, kind, 2024))
+        distinct = set()
+        for w in range(nwin):
+            nat = bytes(rows[w * (r + 1)]).decode()
+            assert nat == tr[w * step:w * step + W]
+            for k in range(1, r + 1):
+                s = bytes(rows[w * (r + 1) + k]).decode()
+                distinct.add(s)
+                if kind == _lib.SHUFFLE_MONO:
+                    assert Counter(s) == Counter(nat)
+                else:
+                    assert s[0] == nat[0] and s[-1] == nat[-1]
+                    assert Counter(zip(s, s[1:])) == Counter(zip(nat, nat[1:]))
+        assert len(distinct) == nwin * r  # no repeated shuffle
+        part = gpu_engine.shuffle_windows(tr, W, step, 7, 5, r, kind, 2024)
+        assert (ascii_rows(part) == rows[7 * (r + 1):12 * (r + 1)]).all()
+        other = gpu_engine.shuffle_windows(tr, W, step, 0, 2, r, kind, 2025)
+        assert (ascii_rows(other)[1] != rows[1]).any()  # the seed matters
+
+
+def test_mono_shuffle_is_close_to_uniform(gpu_engine):
+    tr = "ACGU" * 5
+    rows = gpu_engine.shuffle_windows(tr, 20, 1, 0, 1, 20000, _lib.SHUFFLE_MONO, 1)[1:]
+    freq = (rows == 1).mean(axis=0)  # P(A at each position) should be 1/4 everywhere
+    assert np.abs(freq - 0.25).max() < 0.02
+
+
+def build_expected_rows(oracle, eng, seq, W, step, r, kind, seed):
+    starts = scanmod.window_starts(len(seq), W, step)
+    rows = ascii_rows(eng.shuffle_windows(seq, W, step, 0, len(starts), r, kind, seed))
+    E = oracle.mfe_batch(rows).reshape(len(starts), r + 1)
+    structs, cens, eds = [], [], []
+    for i in starts:
+        frag = scanmod.transcribe(seq[i:i + W])
+        structs.append(oracle.mfe(frag)[0])
+        o = oracle.pf(frag)
+        cens.append(o["centroid"])
+        eds.append(o["mean_bp_dist"])
+    return scanmod.rows_from_results(seq, starts, W, r, 37, E, structs, cens, np.array(eds))
+
+
+def test_config1_tsv_bytes_equal_oracle_built_tsv(gpu_engine, oracle):
+    # BASELINE config 1: 1 kb, W=120, step=40, 10 shuffles -> 23 windows / 253 folds
+    seq = synth_transcript(1000, 1)
+    for kind_name, kind in (("di", _lib.SHUFFLE_DI), ("mono", _lib.SHUFFLE_MONO)):
+        got = scanmod.scan_record(seq, 120, 40, 10, kind_name, 37, gpu_engine, seed=3)
+        exp = build_expected_rows(oracle, gpu_engine, seq, 120, 40, 10, kind, 3)
+        assert len(got) == 23 and got == exp
+
+
+def test_config2_all_energies_equal_oracle(gpu_engine, oracle):
+    # BASELINE config 2: 10 kb, W=120, step=10, 30 shuffles -> 989 windows / 30 659 folds
+    seq = synth_transcript(10000, 2)
+    res = gpu_engine.scan(seq, 120, 10, 0, 989, 30, _lib.SHUFFLE_DI, 11)
+    rows = ascii_rows(gpu_engine.shuffle_windows(seq, 120, 10, 0, 989, 30, _lib.SHUFFLE_DI, 11))
+    assert (res["energies"].reshape(-1) == oracle.mfe_batch(rows)).all()
+    for w in range(0, 989, 97):
+        s = seq[w * 10:w * 10 + 120]
+        assert oracle.mfe(s)[0] == res["structure"][w]
+        o = oracle.pf(s)
+        assert o["centroid"] == res["centroid"][w] and abs(o["mean_bp_dist"] - res["ens_div"][w]) < PF_TOL
+
+
+def test_config3_size_independent_properties(gpu_engine, oracle):
+    # BASELINE config 3 shape (30 kb, W=120, step=1, 100 shuffles) on a 3 000-window slice of it, plus
+    # properties that do not need the oracle at full size
+    seq = synth_transcript(30000, 3)
+    W, r = 120, 100
+    nwin_total = len(seq) - W + 1
+    assert nwin_total == 29881
+    lo, n = 12000, 3000
+    flags = _lib.SCAN_NO_PF | _lib.SCAN_NO_TRACE
+    full = gpu_engine.scan(seq, W, 1, lo, n, r, _lib.SHUFFLE_DI, 17, flags)["energies"]
+    # (a) sharding / batching invariance: any sub-range reproduces the same numbers
+    a = gpu_engine.scan(seq, W, 1, lo, 1000, r, _lib.SHUFFLE_DI, 17, flags)["energies"]
+    b = gpu_engine.scan(seq, W, 1, lo + 1000, 2000, r, _lib.SHUFFLE_DI, 17, flags)["energies"]
+    assert (np.concatenate([a, b]) == full).all()
+    assert int(a.sum(dtype=np.int64) + b.sum(dtype=np.int64)) == int(full.sum(dtype=np.int64))
+    # (b) native column == independent energies() call on the window strings
+    nat = gpu_engine.mfe_batch([seq[i:i + W] for i in range(lo, lo + n)])
+    assert (nat == full[:, 0]).all()
+    # (c) oracle on a random sample of (window, shuffle) cells
+    rows = ascii_rows(gpu_engine.shuffle_windows(seq, W, 1, lo + 500, 40, r, _lib.SHUFFLE_DI, 17))
+    assert (oracle.mfe_batch(rows).reshape(40, r + 1) == full[500:540]).all()
+    # (d) both kernels agree on everything
+    gpu_engine.set_kernel_mode(1)
+    try:
+        slow = gpu_engine.scan(seq, W, 1, lo, 200, r, _lib.SHUFFLE_DI, 17, flags)["energies"]
+    finally:
+        gpu_engine.set_kernel_mode(0)
+    assert (slow == full[:200]).all()
+    # (e) idempotence
+    again = gpu_engine.scan(seq, W, 1, lo, n, r, _lib.SHUFFLE_DI, 17, flags)["energies"]
+    assert (again == full).all()
+
+
+def test_planted_hairpin_gets_a_negative_zscore(gpu_engine):
+    rng = np.random.default_rng(9)
+    bg = "".join("ACGU"[k] for k in rng.choice(4, 400, p=[0.3, 0.2, 0.2, 0.3]))
+    stem = "GGCGCGGCACCGUCCGCGGAACAAACGG"
+    comp = stem[::-1].translate(str.maketrans("ACGU", "UGCA"))
+    seq = bg[:140] + stem + "GAAA" + comp + bg[200:]
+    rows = scanmod.scan_record(seq, 120, 20, 50, "di", 37, gpu_engine, seed=1)
+    z = [float(r.split("\t")[4]) for r in rows]
+    assert min(z) < -2.0
+
+
+def test_torch_device_pointer_path_equals_host_path(gpu_engine):
+    import torch
+    seq = synth_transcript(2000, 4)
+    W, step, r = 120, 9, 12
+    nwin = (len(seq) - W) // step + 1
+    host = gpu_engine.scan(seq, W, step, 0, nwin, r, _lib.SHUFFLE_DI, 5)
+    dev = torch.device("cuda:0")
+    tr = torch.tensor(list(seq.encode()), dtype=torch.uint8, device=dev)
+    en = torch.empty((nwin, r + 1), dtype=torch.int32, device=dev)
+    db = torch.zeros((nwin, W + 1), dtype=torch.uint8, device=dev)
+    cen = torch.zeros((nwin, W + 1), dtype=torch.uint8, device=dev)
+    div = torch.zeros(nwin, dtype=torch.float64, device=dev)
+    dG = torch.zeros(nwin, dtype=torch.float64, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    gpu_engine.scan_dev(tr.data_ptr(), len(seq), W, step, 0, nwin, r, _lib.SHUFFLE_DI, 5, 0, en.data_ptr(),
+                        db.data_ptr(), cen.data_ptr(), div.data_ptr(), dG.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert (en.cpu().numpy() == host["energies"]).all()
+    assert [bytes(x[:W]).decode() for x in db.cpu().numpy()] == host["structure"]
+    assert [bytes(x[:W]).decode() for x in cen.cpu().numpy()] == host["centroid"]
+    assert np.array_equal(div.cpu().numpy(), host["ens_div"])
+
+
+def test_scanfoldfunctions_surface_on_gpu(gpu_engine, oracle):
+    from scanfold_amd import RNA, functions as sff, scan_functions as sfn
+    import random
+    random.seed(3)
+    frag = synth_transcript(120, 6)
+    seqlist = [frag] + sff.scramble(frag, 10, "di")
+    el = sff.energies(seqlist, 37, "rnafold")
+    assert el == [float(np.float32(oracle.mfe(s)[1]) / np.float32(100)) for s in seqlist]
+    assert sff.rna_folder((frag, 37, "rnafold")) == el[0] == sfn.rna_folder(frag) == sfn.energies([frag])[0]
+    assert sff.multiprocessing(sff.rna_folder, [(s, 37, "rnafold") for s in seqlist], 12) == el
+    with pytest.raises(UnboundLocalError):
+        sff.energies(seqlist, 37, "rnastructure")
+    with pytest.raises(NotImplementedError):
+        sff.energies(seqlist, 25, "rnafold")
+    assert isinstance(sff.zscore_function(el, 10), float) and 0.0 <= sff.pvalue_function(el, 10) <= 1.0
+    fc = RNA.fold_compound(frag, RNA.md())
+    structure, mfe = fc.mfe()
+    assert (structure, mfe) == (oracle.mfe(frag)[0], el[0]) == RNA.fold(frag)
+    fc.pf()
+    o = oracle.pf(frag)
+    assert fc.centroid()[0] == o["centroid"] and abs(fc.mean_bp_distance() - o["mean_bp_dist"]) < PF_TOL
+
+
+def test_cli_writes_the_reference_named_file(gpu_engine, tmp_path):
+    fa = tmp_path / "t.fa"
+    seq = synth_transcript(400, 12)
+    fa.write_text(">r1 test\n" + seq[:200] + "\n" + seq[200:] + "\n>short\nACGU\n")
+    assert scanmod.main(["-i", str(fa), "-w", "120", "-s", "40", "-r", "10", "-type", "di", "--seed", "4"]) == 0
+    out = tmp_path / "t.fa.forward.win_120.stp_40.rnd_10.shfl_di.txt"
+    lines = out.read_text().split("\n")
+    assert lines[0] == scanmod.header_line("r1").rstrip("\n")
+    assert len(lines) == 1 + 8 + 1 and lines[1].split("\t")[:3] == ["1", "120", "37"]
+    f = lines[1].split("\t")
+    assert len(f) == 10 and len(f[7]) == len(f[8]) == len(f[9]) == 120

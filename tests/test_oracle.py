@@ -1,0 +1,111 @@
+"""What pins the oracle in the absence of any ViennaRNA golden value."""
+import math
+import re
+from functools import lru_cache
+
+import numpy as np
+import pytest
+
+from scanfold_amd import params
+
+KT = (37 + 273.15) * 1.98717
+
+
+def rseq(rng, n, p=None):
+    return "".join("ACGU"[k] for k in rng.choice(4, n, p=p))
+
+
+def count_structures(s):
+    ok = lambda a, b: a + b in ("CG", "GC", "GU", "UG", "AU", "UA")
+
+    @lru_cache(None)
+    def N(i, j):
+        if j - i < 4:
+            return 1
+        t = N(i + 1, j)
+        for k in range(i + 4, j + 1):
+            if ok(s[i], s[k]):
+                t += N(i + 1, k - 1) * N(k + 1, j)
+        return t
+    return N(0, len(s) - 1)
+
+
+def test_v1_bruteforce_equals_dp_and_traceback_evaluates_to_mfe(oracle):
+    rng = np.random.default_rng(0)
+    for t in range(150):
+        s = rseq(rng, int(rng.integers(8, 20)), [0.15, 0.35, 0.35, 0.15] if t % 2 else None)
+        db, e = oracle.mfe(s)
+        be, Z, _, cnt = oracle.brute(s)
+        assert cnt == count_structures(s)
+        assert e == be == oracle.eval_structure(s, db), (s, db, e, be)
+
+
+def test_v1_v3_with_randomised_parameter_tables():
+    from oracle import oracle as orc
+    rng = np.random.default_rng(1)
+    n_multi = 0
+    for seed in range(4):
+        p = params.random_params(seed)
+        if seed % 2:
+            p.rec["MLclosing"] = -200  # make multiloops win
+        orc.set_params(p)
+        for t in range(25):
+            s = rseq(rng, int(rng.integers(10, 21)), [0.15, 0.35, 0.35, 0.15] if t % 2 else None)
+            db, e = orc.mfe(s)
+            be, Z, bpp, _ = orc.brute(s, True)
+            assert e == be == orc.eval_structure(s, db), (seed, s, db)
+            r = orc.pf(s, True)
+            assert abs(-math.log(Z) * KT / 1000 - r["dG"]) < 1e-9
+            assert np.abs(bpp - r["bpp"]).max() < 1e-9
+            n_multi += bool(re.search(r"\([^()]*\([^()]*\)[^()]*\(", db))
+    assert n_multi > 0
+
+
+def test_v2_traceback_energy_on_long_sequences(oracle):
+    rng = np.random.default_rng(2)
+    for n in (30, 60, 120, 200):
+        for _ in range(10):
+            s = rseq(rng, n)
+            db, e = oracle.mfe(s)
+            assert len(db) == n and db.count("(") == db.count(")")
+            assert oracle.eval_structure(s, db) == e
+    assert oracle.mfe("A" * 50) == ("." * 50, 0)
+    assert oracle.mfe("N" * 50)[1] == 0
+    assert oracle.mfe("ACG")[1] == 0
+
+
+def test_v3_partition_function_against_enumeration(oracle):
+    rng = np.random.default_rng(3)
+    for _ in range(40):
+        s = rseq(rng, int(rng.integers(8, 18)))
+        be, Z, bpp, _ = oracle.brute(s, True)
+        r = oracle.pf(s, True)
+        assert abs(-math.log(Z) * KT / 1000 - r["dG"]) < 1e-9
+        assert np.abs(bpp - r["bpp"]).max() < 1e-9
+        assert (r["bpp"].sum(axis=1) <= 1 + 1e-9).all()
+        assert abs(r["mean_bp_dist"] - 2 * (bpp * (1 - bpp)).sum()) < 1e-9
+        cen = ["."] * len(s)
+        for i, j in zip(*np.where(bpp > 0.5)):
+            cen[i - 1], cen[j - 1] = "(", ")"
+        assert "".join(cen) == r["centroid"]
+        assert r["dG"] <= be / 100.0 + 1e-9  # ensemble free energy is below the MFE
+
+
+def test_case_and_t_are_normalised(oracle):
+    assert oracle.mfe("GGGGAAAACCCC") == oracle.mfe("ggggaaaacccc") == oracle.mfe("GGGGAAAACCCC".replace("U", "T"))
+    assert oracle.mfe("GGGGUUUUCCCC") == oracle.mfe("GGGGTTTTCCCC")
+
+
+def test_known_small_answers(oracle):
+    # hand-evaluated with the shipped table: GGGGAAAACCCC = 3 stacks + 4-nt hairpin with GA.. mismatch
+    p = params.default_params().rec
+    db, e = oracle.mfe("GGGGAAAACCCC")
+    assert db == "((((....))))"
+    # G-C closing pairs are type 2; the pair stacked inside is seen reversed (type 1); the exterior stem of a
+    # sequence-spanning helix has no neighbours and GC carries no TerminalAU
+    exp = 3 * p["stack"][2][1] + p["hairpin"][4] + p["mismatchH"][2][1][1]
+    assert e == exp == -540
+    # special tetraloop replaces initiation + mismatch outright
+    db, e = oracle.mfe("GGGGCUUCGGCCCC")
+    assert db == "(((((....)))))" or db.count("(") >= 4
+    assert oracle.eval_structure("GGGGCUUCGGCCCC", db) == e

@@ -54,12 +54,34 @@ class ScanFoldHipError(RuntimeError):
     pass
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch wheels bundle their own libamdhip64 (same SONAME, different file name).  Two HIP runtimes in
+    one process do not work ("No HIP GPUs are available" in whichever initialises second), so when torch is
+    installed its copy is loaded first and this library binds to it by SONAME; torch later finds the same
+    file already loaded.  Without torch the system runtime under /opt/rocm is used."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load_library(path=LIB_PATH):
     """dlopen the C-ABI library and declare every prototype; raises if it or a symbol is missing."""
     if not os.path.exists(path):
         raise ScanFoldHipError(
             "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
+    if os.path.abspath(path) == os.path.abspath(LIB_PATH):
+        _share_hip_runtime_with_torch()
     lib = ctypes.CDLL(path)
     for name, (res, args) in _EXPORTS.items():
         fn = getattr(lib, name)

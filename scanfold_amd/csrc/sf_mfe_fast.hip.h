@@ -3,19 +3,32 @@
 // Replaces energies(seq_list) -> rna_folder -> RNA.fold(seq) (ScanFold-Scan.py:244-246,253-262;
 // ScanFoldFunctions.py:774-789,805-814): r+1 folds per window whose structures the caller throws away.
 //
-// One workgroup folds one sequence at a time (persistent grid, sequences dealt round-robin).  Thread t owns
-// cell (i = t+1, j = i+d) of anti-diagonal d; one barrier per diagonal.  LDS holds, per workgroup:
-//   fML   int16, full triangle, diagonal-major      (the O(W^3) multiloop split reads every diagonal)
-//   CI, C1N, CB  int16, rolling window of SF_FAST_NR diagonals — an interior loop reaches at most MAXLOOP+2
-//         diagonals inwards, so older diagonals of c are dead.  They hold c pre-added with the inner
-//         pair's own terms so the 496-candidate search is one LDS read + add + min per candidate:
+// One workgroup folds one sequence at a time (persistent grid, sequences dealt round-robin); one barrier
+// per anti-diagonal d.  Thread mapping: a thread owns a CENTRE s = i+j (two centres, one per parity of d):
+// on diagonal d it handles the cell i = v - d/2, j = i+d with v = (tid+OFF) mod NT.  The cell of the same
+// thread two diagonals later is (i-1, j+1), the cell that encloses it — which makes the interior-loop search
+// incremental (below) with all of its state in registers.
+//
+// LDS per workgroup (W=120: 40.6 kB -> 4 workgroups per CU):
+//   fML   int16 full triangle, diagonal-major          (the O(W^3) multiloop split reads every diagonal)
+//   CI, C1N, CB  int16, rolling window of SF_FAST_NR diagonals of c, pre-added with the inner pair's terms:
 //           CI  = c + mismatchI [rtype][S[j+1]][S[i-1]]   generic loops
 //           C1N = c + mismatch1nI[rtype][S[j+1]][S[i-1]]  1 x n loops
 //           CB  = c + TerminalAU(rtype)                   bulges (and, minus that term, the few special loops)
 //   DML   rolling 3 diagonals of min_k fML[i,k]+fML[k+1,j]
-// The size-dependent part of a candidate (loop initiation + asymmetry) is the same for every thread of a
-// diagonal, so it comes from scalar loads (SfFastParams).  c itself is streamed to a device scratch table
-// (int16, 2 B per cell, coalesced) for the exterior-loop pass at the end.
+//   small int16 parameter tables (mismatches, stack, dangles, pair types)
+//
+// Interior loops.  Of the 496 (u1,u2) candidates of a cell, 375 are "generic" (both sides >= 2, not 2x2/2x3):
+//   E = CI[p,q] + internal_loop[u1+u2] + min(max_ninio, ninio*|u1-u2|) + mismatchI[type][S[i+1]][S[j-1]].
+// For fixed total size u, the candidates of (i,j) with u1,u2 >= 3 are exactly the candidates of (i+1,j-1)
+// with total u-2 and the same asymmetry (Lyngso et al. 1999), so with
+//   H[i,j,u] = min_{u1+u2=u, u1,u2>=2} CI[i+1+u1, j-1-u2] + ninio(|u1-u2|)
+// H[i,j,u] = min(H[i+1,j-1,u-2], the two edge candidates u1=2 and u2=2): 2 LDS reads per u instead of u-3,
+// exact (same minimum over the same set).  H lives in registers because (i+1,j-1) is the same thread's
+// previous cell.  Bulges (2 per size), 1 x n loops (2 per size) and the 9 special candidates are direct.
+// Size-dependent terms are wave-uniform and come from scalar registers.
+//
+// c itself is streamed to a device scratch table (int16, coalesced) for the exterior-loop pass at the end.
 //
 // int16 is exact while |energy| < 12000 dcal/mol; a fold that leaves that range (a >120 kcal/mol helix) is
 // appended to an overflow list and redone by the int32 kernel (sf_mfe_full.hip.h), so results never depend
@@ -30,28 +43,28 @@
 #define SF_FAST_OVF (-12000)
 #define SF_FAST_MAXPARAM 2500
 #define SF_FAST_MAXW 256
+#define SF_FAST_BIG 60000
 
 struct SfFastParams {
-  int32_t LT[31][32];  // [u][u1] generic interior: internal_loop[u] + min(max_ninio, |u - 2*u1| * ninio)
-  int32_t L1N[32];     // [n] 1 x n: internal_loop[n+1] + min(max_ninio, (n-1) * ninio)
-  int32_t BUL[32];     // [n] bulge[n]
-  int32_t L23;         // internal_loop[5] + ninio
-  int32_t fast_ok;     // parameter magnitudes allow int16 storage
+  int32_t NIN[32];   // [a]  min(max_ninio, a * ninio)
+  int32_t IL[32];    // [u]  internal_loop[u]
+  int32_t L1N[32];   // [n]  1 x n: internal_loop[n+1] + min(max_ninio, (n-1) * ninio)
+  int32_t BUL[32];   // [n]  bulge[n]
+  int32_t L23;       // internal_loop[5] + ninio
+  int32_t fast_ok;   // parameter magnitudes allow int16 storage
+  // int16 images of the small tables, index t*25 + a*5 + b (t = pair type 0..7)
+  int16_t mmI[200], mm1n[200], mm23[200], mmM[200], mmH[200], mmExt[200];
+  int16_t stack[64];
+  int16_t d5[40], d3[40];
+  uint8_t pair[64];  // [a*8+b]
 };
 
 static inline void sf_fast_build_params(const SfDevParams &D, SfFastParams &F) {
   const sf_params_blob &P = D.P;
   memset(&F, 0, sizeof F);
-  for (int u = 0; u <= 30; u++)
-    for (int u1 = 0; u1 <= u && u1 < 32; u1++) {
-      const int a = u - 2 * u1 < 0 ? 2 * u1 - u : u - 2 * u1;
-      const int nin = a * P.ninio < P.max_ninio ? a * P.ninio : P.max_ninio;
-      F.LT[u][u1] = P.internal_loop[u] + nin;
-    }
-  for (int n = 0; n <= 29; n++) {
-    const int nin = (n - 1) * P.ninio < P.max_ninio ? (n - 1) * P.ninio : P.max_ninio;
-    F.L1N[n] = P.internal_loop[n + 1] + nin;
-  }
+  for (int a = 0; a < 32; a++) F.NIN[a] = a * P.ninio < P.max_ninio ? a * P.ninio : P.max_ninio;
+  for (int u = 0; u <= 30; u++) F.IL[u] = P.internal_loop[u];
+  for (int n = 0; n <= 29; n++) F.L1N[n] = P.internal_loop[n + 1] + F.NIN[n > 0 ? n - 1 : 0];
   for (int n = 0; n <= 30; n++) F.BUL[n] = P.bulge[n];
   F.L23 = P.internal_loop[5] + P.ninio;
   // magnitude check over every finite entry the kernel can add up
@@ -71,28 +84,47 @@ static inline void sf_fast_build_params(const SfDevParams &D, SfFastParams &F) {
   upd(&P.TerminalAU, 1); upd(P.tetra_E, SF_NSPECIAL); upd(P.tri_E, SF_NSPECIAL); upd(P.hexa_E, SF_NSPECIAL);
   for (int s = 0; s <= SF_FAST_MAXW; s++) upd(&D.hp_init[s], 1);
   F.fast_ok = (mx <= SF_FAST_MAXPARAM) ? 1 : 0;
+  auto clamp16 = [](int v) { return (int16_t)(v > 32000 ? 32000 : (v < -32000 ? -32000 : v)); };
+  for (int t = 0; t < 8; t++) {
+    for (int a = 0; a < 5; a++) {
+      for (int b = 0; b < 5; b++) {
+        const int k = t * 25 + a * 5 + b;
+        F.mmI[k] = clamp16(P.mismatchI[t][a][b]);
+        F.mm1n[k] = clamp16(P.mismatch1nI[t][a][b]);
+        F.mm23[k] = clamp16(P.mismatch23I[t][a][b]);
+        F.mmM[k] = clamp16(P.mismatchM[t][a][b]);
+        F.mmH[k] = clamp16(P.mismatchH[t][a][b]);
+        F.mmExt[k] = clamp16(P.mismatchExt[t][a][b]);
+      }
+      F.d5[t * 5 + a] = clamp16(P.dangle5[t][a]);
+      F.d3[t * 5 + a] = clamp16(P.dangle3[t][a]);
+    }
+    for (int u = 0; u < 8; u++) F.stack[t * 8 + u] = clamp16(P.stack[t][u]);
+  }
+  for (int a = 0; a < 8; a++)
+    for (int b = 0; b < 8; b++) F.pair[a * 8 + b] = (uint8_t)D.pair[a][b];
 }
 
 // LDS carve (bytes); every piece a multiple of 4
 struct SfFastLayout {
-  int tri;      // int16 entries of the fML triangle (diagonals >= 4)
-  int off_ci, off_c1n, off_cb, off_dml, off_f5, off_red, off_flag, off_S;
+  int tri;  // int16 entries of the fML triangle (diagonals >= 4)
+  int off_ci, off_c1n, off_cb, off_dml, off_tab, off_red, off_flag, off_S;
   int total;
 };
+#define SF_FAST_TAB_BYTES (5 * 400 + 128 + 80 + 80 + 64)
 static inline __host__ __device__ SfFastLayout sf_fast_layout(int W) {
   SfFastLayout L;
-  const int nd = W - 4;  // diagonals 4..W-1
-  int tri = nd > 0 ? nd * W - (W * (W - 1) / 2 - 6) + 0 : 0;  // sum_{d=4}^{W-1} (W-d)
+  int tri = (W - 4) * W - (W * (W - 1) / 2 - 6);  // sum_{d=4}^{W-1} (W-d)
   if (tri < 0) tri = 0;
   tri = (tri + 1) & ~1;
   L.tri = tri;
   int o = tri * 2;
   const int roll = ((SF_FAST_NR * W + 1) & ~1) * 2;
-  L.off_ci = o; o += roll;
+  L.off_ci = o; o += roll;   // the exterior pass reuses this area for f5[] and the mismatchExt table
   L.off_c1n = o; o += roll;
   L.off_cb = o; o += roll;
   L.off_dml = o; o += ((3 * W + 1) & ~1) * 2;
-  L.off_f5 = o; o += (W + 1) * 4;
+  L.off_tab = o; o += SF_FAST_TAB_BYTES;
   L.off_red = o; o += 8 * 4;
   L.off_flag = o; o += 4;
   L.off_S = o; o += (W + 2 + 3) & ~3;
@@ -100,8 +132,161 @@ static inline __host__ __device__ SfFastLayout sf_fast_layout(int W) {
   return L;
 }
 
-static inline bool sf_fast_w_supported(int W) { return W >= 8 && W <= SF_FAST_MAXW; }
+static inline bool sf_fast_w_supported(int W) { return W >= 16 && W <= SF_FAST_MAXW; }
 static inline int sf_fast_threads(int W) { return W <= 128 ? 128 : 256; }
+
+struct SfFastCtx {
+  int16_t *fML, *CI, *C1N, *CB, *DMLr;
+  const int16_t *tI, *t1n, *t23, *tM, *tH, *tStack, *tD5, *tD3;
+  const uint8_t *tPair, *S;
+  const SfDevParams *D;
+  const SfFastParams *F;
+  int16_t *cg;
+  int W, TAU, MLbase, MLclosing, MLintern;
+};
+
+#define SF_TIDX(t, a, b) ((t)*25 + (a)*5 + (b))
+
+// One anti-diagonal for one thread.  H: this parity's per-size minima of the generic candidates of the
+// enclosed cell (i+1, j-1) on entry, of (i, j) on exit.  slot2 = (d-2) mod NR, slotd = d mod NR.
+__device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, const int i, const bool valid,
+                                             const int slot2, const int slotd, int (&H)[27], int &ovf) {
+  const int W = X.W;
+  if (!valid) return;
+  const int j = i + d, i0 = i - 1;
+  const uint8_t *S = X.S;
+  const int umax = sfd_min(SFD_MAXLOOP, d - 2 - (SFD_TURN + 1));
+  const int type = X.tPair[S[i] * 8 + S[j]];
+  const int si1 = S[i + 1], sj1 = S[j - 1];
+// fML triangle without diagonals 0..3: base(d) = sum_{k=4}^{d-1} (W-k)
+#define FBASE(dd) (((dd)-4) * W - ((dd) * ((dd)-1) / 2 - 6))
+// row of diagonal d-2-u in the rolling tables
+#define ROW(u) ((slot2 - (u) < 0 ? slot2 - (u) + SF_FAST_NR : slot2 - (u)) * W)
+
+  // ---- pass 1 (every cell): per-size minima of the generic interior candidates ----
+#pragma unroll
+  for (int u = 30; u >= 6; --u) {
+    if (u <= umax) {
+      const int16_t *row = X.CI + ROW(u) + i0;
+      const int e = sfd_min(row[3], row[u - 1]) + X.F->NIN[u - 4];  // u1 = 2 and u2 = 2
+      H[u - 4] = sfd_min(e, H[u - 6]);
+    }
+  }
+  if (umax >= 5) {
+    const int16_t *row = X.CI + ROW(5) + i0;
+    H[1] = sfd_min(row[3], row[4]) + X.F->NIN[1];
+  }
+  if (umax >= 4) H[0] = X.CI[ROW(4) + i0 + 3] + X.F->NIN[0];
+
+  // ---- pass 2 (pairable cells): c[i,j] ----
+  int c = SF_INF16;
+  if (type) {
+    const int TAU = X.TAU;
+    const sf_params_blob &P = X.D->P;
+    int e;
+    if (d <= 7) e = sfd_hairpin(X.D, S, i, j, type);  // sizes 3, 4, 6 may be special loops
+    else e = X.D->hp_init[d - 1] + X.tH[SF_TIDX(type, si1, sj1)];
+    if (umax >= 0) {
+      const int tau_out = type > 2 ? TAU : 0;
+      const int16_t *st = X.tStack + type * 8;
+      {  // stack
+        const int t2r = sfd_rtype(X.tPair[si1 * 8 + sj1]);
+        e = sfd_min(e, X.CB[ROW(0) + i0 + 1] - (t2r > 2 ? TAU : 0) + st[t2r]);
+      }
+      if (umax >= 1) {  // one-nucleotide bulges keep the stack
+        const int b1 = X.F->BUL[1];
+        const int16_t *row = X.CB + ROW(1) + i0;
+        const int ta = sfd_rtype(X.tPair[si1 * 8 + S[j - 2]]);  // (i+1, j-2)
+        e = sfd_min(e, row[1] - (ta > 2 ? TAU : 0) + b1 + st[ta]);
+        const int tb = sfd_rtype(X.tPair[S[i + 2] * 8 + sj1]);  // (i+2, j-1)
+        e = sfd_min(e, row[2] - (tb > 2 ? TAU : 0) + b1 + st[tb]);
+      }
+      if (umax >= 2) {  // 1 x 1: (i+2, j-2)
+        const int t2r = sfd_rtype(X.tPair[S[i + 2] * 8 + S[j - 2]]);
+        e = sfd_min(e, X.CB[ROW(2) + i0 + 2] - (t2r > 2 ? TAU : 0) + P.int11[type][t2r][si1][sj1]);
+      }
+      if (umax >= 3) {  // 1 x 2 and 2 x 1
+        const int16_t *row = X.CB + ROW(3) + i0;
+        const int ta = sfd_rtype(X.tPair[S[i + 2] * 8 + S[j - 3]]);  // (i+2, j-3), sq1 = S[j-2]
+        e = sfd_min(e, row[2] - (ta > 2 ? TAU : 0) + P.int21[type][ta][si1][S[j - 2]][sj1]);
+        const int tb = sfd_rtype(X.tPair[S[i + 3] * 8 + S[j - 2]]);  // (i+3, j-2), sp1 = S[i+2]
+        e = sfd_min(e, row[3] - (tb > 2 ? TAU : 0) + P.int21[tb][type][sj1][si1][S[i + 2]]);
+      }
+      if (umax >= 4) {  // 2 x 2: (i+3, j-3)
+        const int t2r = sfd_rtype(X.tPair[S[i + 3] * 8 + S[j - 3]]);
+        e = sfd_min(e, X.CB[ROW(4) + i0 + 3] - (t2r > 2 ? TAU : 0) + P.int22[type][t2r][si1][S[i + 2]][S[j - 2]][sj1]);
+      }
+      if (umax >= 5) {  // 2 x 3 and 3 x 2
+        const int16_t *row = X.CB + ROW(5) + i0;
+        const int m23 = X.t23[SF_TIDX(type, si1, sj1)] + X.F->L23;
+        const int ta = sfd_rtype(X.tPair[S[i + 3] * 8 + S[j - 4]]);  // (i+3, j-4); sp1 = S[i+2], sq1 = S[j-3]
+        e = sfd_min(e, row[3] - (ta > 2 ? TAU : 0) + m23 + X.t23[SF_TIDX(ta, S[j - 3], S[i + 2])]);
+        const int tb = sfd_rtype(X.tPair[S[i + 4] * 8 + S[j - 3]]);  // (i+4, j-3); sp1 = S[i+3], sq1 = S[j-2]
+        e = sfd_min(e, row[4] - (tb > 2 ? TAU : 0) + m23 + X.t23[SF_TIDX(tb, S[j - 2], S[i + 3])]);
+      }
+      // bulges (size u >= 2), 1 x n loops (total size u >= 4) and the generic minima, one rolling row per u
+      int gb = SF_FAST_BIG, g1 = SF_FAST_BIG, gg = SF_FAST_BIG;
+#pragma unroll
+      for (int u = 2; u <= 30; ++u) {
+        if (u <= umax) {
+          const int rw = ROW(u) + i0;
+          gb = sfd_min(gb, sfd_min(X.CB[rw + 1], X.CB[rw + 1 + u]) + X.F->BUL[u]);
+          if (u >= 4) g1 = sfd_min(g1, sfd_min(X.C1N[rw + 2], X.C1N[rw + u]) + X.F->L1N[u - 1]);
+          if (u >= 6) gg = sfd_min(gg, H[u - 4] + X.F->IL[u]);
+        }
+      }
+      e = sfd_min(e, gb + tau_out);
+      e = sfd_min(e, g1 + X.t1n[SF_TIDX(type, si1, sj1)]);
+      e = sfd_min(e, gg + X.tI[SF_TIDX(type, si1, sj1)]);
+    }
+    // multiloop closed by (i,j)
+    {
+      const int tr = sfd_rtype(type);
+      const int dml = X.DMLr[((d - 2) % 3) * W + i0 + 1];
+      e = sfd_min(e, dml + X.tM[SF_TIDX(tr, sj1, si1)] + (tr > 2 ? TAU : 0) + X.MLintern + X.MLclosing);
+    }
+    c = e;
+    if (c < SF_FAST_OVF) ovf = 1;
+  }
+
+  // ---- publish the cell ----
+  const int rbd = slotd * W + i0;
+  int f = SF_FAST_BIG;
+  if (type) {
+    const int tr = sfd_rtype(type);
+    const int sp1 = S[i - 1], sq1 = S[j + 1];
+    const int tau_in = tr > 2 ? X.TAU : 0;
+    X.CI[rbd] = (int16_t)(c + X.tI[SF_TIDX(tr, sq1, sp1)]);
+    X.C1N[rbd] = (int16_t)(c + X.t1n[SF_TIDX(tr, sq1, sp1)]);
+    X.CB[rbd] = (int16_t)(c + tau_in);
+    int stem;  // E_MLstem(type, S[i-1], S[j+1]); sequence ends have dangles only
+    if (i > 1 && j < W) stem = X.tM[SF_TIDX(type, sp1, sq1)];
+    else if (i > 1) stem = X.tD5[type * 5 + sp1];
+    else if (j < W) stem = X.tD3[type * 5 + sq1];
+    else stem = 0;
+    f = c + stem + tau_in + X.MLintern;
+  } else {
+    X.CI[rbd] = SF_INF16; X.C1N[rbd] = SF_INF16; X.CB[rbd] = SF_INF16;
+  }
+  X.cg[d * W + i0] = (int16_t)c;
+  // fML[i,j]
+  if (d > SFD_TURN + 1) {
+    const int fb = FBASE(d - 1);
+    f = sfd_min(f, sfd_min(X.fML[fb + i0 + 1], X.fML[fb + i0]) + X.MLbase);
+  }
+  int dec = SF_FAST_BIG;
+  {
+    const int16_t *fa = X.fML + i0;       // fML[i, i+m]   = fa[FBASE(m)]
+    const int16_t *fb2 = X.fML + i0 + 1;  // fML[i+m+1, j] = fb2[FBASE(d-m-1) + m]
+#pragma unroll 4
+    for (int m = SFD_TURN + 1; m <= d - SFD_TURN - 2; m++) dec = sfd_min(dec, fa[FBASE(m)] + fb2[FBASE(d - m - 1) + m]);
+  }
+  f = sfd_min(f, dec);
+  if (f < SF_FAST_OVF) ovf = 1;
+  X.DMLr[(d % 3) * W + i0] = (int16_t)(dec > SF_FAST_THRESH ? SF_INF16 : dec);
+  X.fML[FBASE(d) + i0] = (int16_t)(f > SF_FAST_THRESH ? SF_INF16 : f);
+#undef ROW
+}
 
 template <int NT>
 __global__ __launch_bounds__(NT) void sf_mfe_fast_kernel(const uint8_t *__restrict__ seqs, int n, int W,
@@ -111,162 +296,96 @@ __global__ __launch_bounds__(NT) void sf_mfe_fast_kernel(const uint8_t *__restri
                                                          int *__restrict__ ovf_cnt, int *__restrict__ ovf_list) {
   SF_DYN_SMEM(smem);
   const SfFastLayout Lo = sf_fast_layout(W);
-  int16_t *fML = (int16_t *)smem;
-  int16_t *CI = (int16_t *)(smem + Lo.off_ci);
-  int16_t *C1N = (int16_t *)(smem + Lo.off_c1n);
-  int16_t *CB = (int16_t *)(smem + Lo.off_cb);
-  int16_t *DMLr = (int16_t *)(smem + Lo.off_dml);
-  int32_t *f5s = (int32_t *)(smem + Lo.off_f5);
+  SfFastCtx X;
+  X.fML = (int16_t *)smem;
+  X.CI = (int16_t *)(smem + Lo.off_ci);
+  X.C1N = (int16_t *)(smem + Lo.off_c1n);
+  X.CB = (int16_t *)(smem + Lo.off_cb);
+  X.DMLr = (int16_t *)(smem + Lo.off_dml);
+  int16_t *tab = (int16_t *)(smem + Lo.off_tab);
+  X.tI = tab; X.t1n = tab + 200; X.t23 = tab + 400; X.tM = tab + 600; X.tH = tab + 800;
+  X.tStack = tab + 1000; X.tD5 = tab + 1064; X.tD3 = tab + 1104;
+  uint8_t *tPair = (uint8_t *)(tab + 1144);
+  X.tPair = tPair;
   int32_t *red = (int32_t *)(smem + Lo.off_red);
   int32_t *flag = (int32_t *)(smem + Lo.off_flag);
   uint8_t *S = (uint8_t *)(smem + Lo.off_S);
+  X.S = S;
+  X.D = D; X.F = F; X.W = W;
+  X.TAU = D->P.TerminalAU; X.MLbase = D->P.MLbase; X.MLclosing = D->P.MLclosing; X.MLintern = D->P.MLintern[1];
+  // exterior pass aliases (the rolling CI area is dead by then)
+  int32_t *f5s = (int32_t *)(smem + Lo.off_ci);
+  int16_t *tExt = (int16_t *)(smem + Lo.off_ci + (((W + 1) * 4 + 3) & ~3));
 
   const int tid = threadIdx.x;
-  const sf_params_blob &P = D->P;
-  int16_t *cg = cg_all + (size_t)blockIdx.x * W * W;  // c[d][i0] for the exterior pass
-  const int TAU = P.TerminalAU;
-  const int MLbase = P.MLbase, MLclosing = P.MLclosing;
-// fML triangle without diagonals 0..3: base(d) = sum_{k=4}^{d-1} (W-k)
-#define FBASE(d) (((d)-4) * W - ((d) * ((d)-1) / 2 - 6))
-#define RB(dd) (((dd) % SF_FAST_NR) * W)
+  X.cg = cg_all + (size_t)blockIdx.x * W * W;  // c[d][i0] for the exterior pass
+  // parameter tables -> LDS, once per workgroup
+  for (int x = tid; x < 200; x += NT) {
+    tab[x] = F->mmI[x]; tab[200 + x] = F->mm1n[x]; tab[400 + x] = F->mm23[x]; tab[600 + x] = F->mmM[x];
+    tab[800 + x] = F->mmH[x];
+  }
+  for (int x = tid; x < 64; x += NT) { tab[1000 + x] = F->stack[x]; tPair[x] = F->pair[x]; }
+  for (int x = tid; x < 40; x += NT) { tab[1064 + x] = F->d5[x]; tab[1104 + x] = F->d3[x]; }
+
+  // centre-based thread mapping: v = (tid + OFF) mod NT, cell i = v - d/2
+  const int OFF = (NT > 64) ? (((W + 1) >> 1) - 32 + NT) & (NT - 1) : 0;
+  const int v = (tid + OFF) & (NT - 1);
 
   for (int seq = blockIdx.x; seq < n; seq += gridDim.x) {
     const uint8_t *src = seqs + (size_t)seq * W;
     __syncthreads();
     for (int x = tid; x < W; x += NT) S[x + 1] = sf_encode_nt(src[x]);
-    if (tid == 0) { S[0] = 0; S[W + 1] = 0; f5s[0] = 0; flag[0] = 0; }
-    for (int x = tid; x < 3 * W; x += NT) DMLr[x] = SF_INF16;  // diagonals 2,3 have no multiloop split
+    if (tid == 0) { S[0] = 0; S[W + 1] = 0; flag[0] = 0; }
+    for (int x = tid; x < 3 * W; x += NT) X.DMLr[x] = SF_INF16;  // diagonals 2,3 have no multiloop split
     __syncthreads();
     int ovf = 0;
+    int Ha[27], Hb[27];
+#pragma unroll
+    for (int k = 0; k < 27; k++) { Ha[k] = SF_FAST_BIG; Hb[k] = SF_FAST_BIG; }
 
-    for (int d = SFD_TURN + 1; d < W; d++) {
-      const int i = tid + 1, j = i + d, i0 = tid;
-      if (j <= W) {
-        const int type = D->pair[S[i]][S[j]];
-        int c = SF_INF16;
-        if (type) {
-          int e = sfd_hairpin(D, S, i, j, type);
-          const int umax = sfd_min(SFD_MAXLOOP, d - 2 - (SFD_TURN + 1));
-          const int si1 = S[i + 1], sj1 = S[j - 1];
-          if (umax >= 0) {
-            const int tau_out = type > 2 ? TAU : 0;
-            {  // stack
-              const int t2r = sfd_rtype(D->pair[si1][sj1]);
-              const int cc = CB[RB(d - 2) + i0 + 1] - (t2r > 2 ? TAU : 0);
-              e = sfd_min(e, cc + P.stack[type][t2r]);
-            }
-            if (umax >= 1) {  // bulges of one nucleotide keep the stack
-              const int b1 = F->BUL[1];
-              const int ta = sfd_rtype(D->pair[si1][S[j - 2]]);  // (i+1, j-2)
-              const int ca = CB[RB(d - 3) + i0 + 1] - (ta > 2 ? TAU : 0);
-              e = sfd_min(e, ca + b1 + P.stack[type][ta]);
-              const int tb = sfd_rtype(D->pair[S[i + 2]][sj1]);  // (i+2, j-1)
-              const int cb = CB[RB(d - 3) + i0 + 2] - (tb > 2 ? TAU : 0);
-              e = sfd_min(e, cb + b1 + P.stack[type][tb]);
-            }
-            // longer bulges: c + TerminalAU(inner) is pre-added
-            for (int nn = 2; nn <= umax; nn++) {
-              const int add = F->BUL[nn] + tau_out;
-              const int rb = RB(d - 2 - nn);
-              const int v1 = CB[rb + i0 + 1];       // u1 = 0, u2 = nn : (i+1, j-1-nn)
-              const int v2 = CB[rb + i0 + 1 + nn];  // u1 = nn, u2 = 0 : (i+1+nn, j-1)
-              e = sfd_min(e, sfd_min(v1, v2) + add);
-            }
-            if (umax >= 2) {  // 1 x 1
-              const int t2r = sfd_rtype(D->pair[S[i + 2]][S[j - 2]]);
-              const int cc = CB[RB(d - 4) + i0 + 2] - (t2r > 2 ? TAU : 0);
-              e = sfd_min(e, cc + P.int11[type][t2r][si1][sj1]);
-            }
-            if (umax >= 3) {  // 1 x 2 and 2 x 1
-              const int ta = sfd_rtype(D->pair[S[i + 2]][S[j - 3]]);  // u1=1,u2=2: (i+2, j-3), sq1 = S[j-2]
-              const int ca = CB[RB(d - 5) + i0 + 2] - (ta > 2 ? TAU : 0);
-              e = sfd_min(e, ca + P.int21[type][ta][si1][S[j - 2]][sj1]);
-              const int tb = sfd_rtype(D->pair[S[i + 3]][S[j - 2]]);  // u1=2,u2=1: (i+3, j-2), sp1 = S[i+2]
-              const int cb = CB[RB(d - 5) + i0 + 3] - (tb > 2 ? TAU : 0);
-              e = sfd_min(e, cb + P.int21[tb][type][sj1][si1][S[i + 2]]);
-            }
-            if (umax >= 4) {
-              {  // 2 x 2: (i+3, j-3)
-                const int t2r = sfd_rtype(D->pair[S[i + 3]][S[j - 3]]);
-                const int cc = CB[RB(d - 6) + i0 + 3] - (t2r > 2 ? TAU : 0);
-                e = sfd_min(e, cc + P.int22[type][t2r][si1][S[i + 2]][S[j - 2]][sj1]);
-              }
-              // 1 x n and n x 1, n >= 3 (total size n+1 <= umax)
-              const int m1 = P.mismatch1nI[type][si1][sj1];
-              for (int nn = 3; nn + 1 <= umax; nn++) {
-                const int add = F->L1N[nn] + m1;
-                const int rb = RB(d - 3 - nn);
-                const int v1 = C1N[rb + i0 + 2];       // u1 = 1, u2 = nn : (i+2, j-1-nn)
-                const int v2 = C1N[rb + i0 + 1 + nn];  // u1 = nn, u2 = 1 : (i+1+nn, j-2)
-                e = sfd_min(e, sfd_min(v1, v2) + add);
-              }
-            }
-            if (umax >= 5) {  // 2 x 3 and 3 x 2
-              const int m23 = P.mismatch23I[type][si1][sj1] + F->L23;
-              const int ta = sfd_rtype(D->pair[S[i + 3]][S[j - 4]]);  // u1=2,u2=3: (i+3, j-4); sp1=S[i+2], sq1=S[j-3]
-              const int ca = CB[RB(d - 7) + i0 + 3] - (ta > 2 ? TAU : 0);
-              e = sfd_min(e, ca + m23 + P.mismatch23I[ta][S[j - 3]][S[i + 2]]);
-              const int tb = sfd_rtype(D->pair[S[i + 4]][S[j - 3]]);  // u1=3,u2=2: (i+4, j-3); sp1=S[i+3], sq1=S[j-2]
-              const int cb = CB[RB(d - 7) + i0 + 4] - (tb > 2 ? TAU : 0);
-              e = sfd_min(e, cb + m23 + P.mismatch23I[tb][S[j - 2]][S[i + 3]]);
-            }
-            if (umax >= 6) {  // generic loops: both sides >= 2, not 2x2 / 2x3 / 3x2
-              int g = SF_INF16 * 2;
-              for (int u = 6; u <= umax; u++) {
-                const int rb = RB(d - 2 - u) + i0 + 1;
-                const int32_t *lt = F->LT[u];
-                for (int u1 = 2; u1 <= u - 2; u1++) g = sfd_min(g, CI[rb + u1] + lt[u1]);
-              }
-              e = sfd_min(e, g + P.mismatchI[type][si1][sj1]);
-            }
-          }
-          // multiloop closed by (i,j)
-          const int dml = DMLr[((d - 2) % 3) * W + i0 + 1];
-          e = sfd_min(e, dml + sfd_mlstem(D, sfd_rtype(type), sj1, si1) + MLclosing);
-          c = e;
-          if (c < SF_FAST_OVF) ovf = 1;
-        }
-        // publish the cell
-        const int rbd = RB(d) + i0;
-        int f = SF_INF16 * 2;
-        if (type) {
-          const int tr = sfd_rtype(type);
-          const int sp1 = S[i - 1], sq1 = S[j + 1];
-          CI[rbd] = (int16_t)(c + P.mismatchI[tr][sq1][sp1]);
-          C1N[rbd] = (int16_t)(c + P.mismatch1nI[tr][sq1][sp1]);
-          CB[rbd] = (int16_t)(c + (tr > 2 ? TAU : 0));
-          f = c + sfd_mlstem(D, type, i > 1 ? sp1 : -1, j < W ? sq1 : -1);
-        } else {
-          CI[rbd] = SF_INF16; C1N[rbd] = SF_INF16; CB[rbd] = SF_INF16;
-        }
-        cg[d * W + i0] = (int16_t)c;
-        // fML[i,j]
-        if (d > SFD_TURN + 1) {
-          const int fb = FBASE(d - 1);
-          f = sfd_min(f, sfd_min(fML[fb + i0 + 1], fML[fb + i0]) + MLbase);
-        }
-        int dec = SF_INF16 * 2;
-        for (int m = SFD_TURN + 1; m <= d - SFD_TURN - 2; m++)
-          dec = sfd_min(dec, fML[FBASE(m) + i0] + fML[FBASE(d - m - 1) + i0 + m + 1]);
-        f = sfd_min(f, dec);
-        if (f < SF_FAST_OVF) ovf = 1;
-        DMLr[(d % 3) * W + i0] = (int16_t)(dec > SF_FAST_THRESH ? SF_INF16 : dec);
-        fML[FBASE(d) + i0] = (int16_t)(f > SF_FAST_THRESH ? SF_INF16 : f);
+    int slot2 = 2, slotd = 4;  // (d-2) mod NR and d mod NR for d = 4
+    for (int d = SFD_TURN + 1; d < W; d += 2) {
+      {
+        const int i = v - (d >> 1);
+        const bool valid = (i >= 1) && (i + d <= W);
+        if (__ballot(valid)) sf_fast_cell(X, d, i, valid, slot2, slotd, Ha, ovf);
       }
       __syncthreads();
+      slot2 = slot2 + 1 == SF_FAST_NR ? 0 : slot2 + 1;
+      slotd = slotd + 1 == SF_FAST_NR ? 0 : slotd + 1;
+      if (d + 1 < W) {
+        const int d1 = d + 1;
+        const int i = v - (d1 >> 1);
+        const bool valid = (i >= 1) && (i + d1 <= W);
+        if (__ballot(valid)) sf_fast_cell(X, d1, i, valid, slot2, slotd, Hb, ovf);
+      }
+      __syncthreads();
+      slot2 = slot2 + 1 == SF_FAST_NR ? 0 : slot2 + 1;
+      slotd = slotd + 1 == SF_FAST_NR ? 0 : slotd + 1;
     }
 
-    // exterior loop (same recurrence as sf_mfe_full_kernel)
+    // exterior loop (same recurrence as sf_mfe_full_kernel); thread t handles i = t+1 here.
+    // A thread reads c values other threads wrote to device memory: the barriers above order them.
     if (ovf) flag[0] = 1;
+    for (int x = tid; x < 200; x += NT) tExt[x] = F->mmExt[x];
+    if (tid == 0) f5s[0] = 0;
+    __syncthreads();
     for (int j = 1; j <= W; j++) {
-      int v = SF_INF16 * 4;
+      int val = SF_FAST_BIG * 2;
       const int i = tid + 1;
       if (i + SFD_TURN + 1 <= j) {
-        const int type = D->pair[S[i]][S[j]];
-        if (type) v = f5s[i - 1] + cg[(j - i) * W + i - 1] + sfd_extloop(D, type, i > 1 ? S[i - 1] : -1, j < W ? S[j + 1] : -1);
+        const int type = tPair[S[i] * 8 + S[j]];
+        if (type) {
+          int ext;
+          if (i > 1 && j < W) ext = tExt[SF_TIDX(type, S[i - 1], S[j + 1])];
+          else if (i > 1) ext = X.tD5[type * 5 + S[i - 1]];
+          else if (j < W) ext = X.tD3[type * 5 + S[j + 1]];
+          else ext = 0;
+          val = f5s[i - 1] + X.cg[(j - i) * W + i - 1] + ext + (type > 2 ? X.TAU : 0);
+        }
       }
-      v = sf_block_min(v, red);
-      if (tid == 0) f5s[j] = sfd_min(f5s[j - 1], v);
+      val = sf_block_min(val, red);
+      if (tid == 0) f5s[j] = sfd_min(f5s[j - 1], val);
       __syncthreads();
     }
     if (tid == 0) {
@@ -278,7 +397,6 @@ __global__ __launch_bounds__(NT) void sf_mfe_fast_kernel(const uint8_t *__restri
     }
   }
 #undef FBASE
-#undef RB
 }
 
 static inline hipError_t sf_fast_configure() {

@@ -158,7 +158,7 @@ int max_resident_blocks() { return g.n_cu * 4; }
 
 // FULL kernel over n items; see sf_mfe_full_kernel for the indexing arguments
 int launch_full(const uint8_t *d_seqs, const int *d_idx, const int *d_count, int n, int row_stride, int mfe_stride,
-                int W, int32_t *d_mfe, char *d_db, hipStream_t st) {
+                int W, int32_t *d_mfe, char *d_db, int db_stride, hipStream_t st) {
   if (n <= 0) return SF_OK;
   int grid = n < max_resident_blocks() ? n : max_resident_blocks();
   int rc = ensure(g.full_scratch, (size_t)grid * SF_FULL_SCRATCH_INTS(W) * sizeof(int32_t));
@@ -166,7 +166,7 @@ int launch_full(const uint8_t *d_seqs, const int *d_idx, const int *d_count, int
   rc = ensure(g.status, sizeof(int));
   if (rc) return rc;
   SF_LAUNCH(sf_mfe_full_kernel, grid, block_threads(W), 0, st, d_seqs, d_idx, d_count, n, row_stride, mfe_stride, W,
-            (const SfDevParams *)g.dP, (int32_t *)g.full_scratch.p, d_mfe, d_db, (int *)g.status.p);
+            (const SfDevParams *)g.dP, (int32_t *)g.full_scratch.p, d_mfe, d_db, db_stride, (int *)g.status.p);
   HIPCHK(hipGetLastError());
   return SF_OK;
 }
@@ -183,8 +183,10 @@ int launch_pf(const uint8_t *d_seqs, int n, int row_stride, int W, double *d_dG,
   return SF_OK;
 }
 
-// energies of n rows: LDS-resident int16 kernel, then the exact int32 kernel on the rows it flagged
-int launch_mfe(const uint8_t *d_seqs, int n, int W, int32_t *d_out, hipStream_t st) {
+// energies of n rows: LDS-resident int16 kernel, then the exact int32 kernel on the rows it flagged.
+// If d_db, every row that is a multiple of trace_stride also gets its structure, row/trace_stride-th string.
+int launch_mfe(const uint8_t *d_seqs, int n, int W, int32_t *d_out, hipStream_t st, int trace_stride = 1,
+               char *d_db = nullptr) {
   if (n <= 0) return SF_OK;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   HIPCHK(hipEventCreate(&e0));
@@ -192,9 +194,10 @@ int launch_mfe(const uint8_t *d_seqs, int n, int W, int32_t *d_out, hipStream_t 
   int rc = SF_OK;
   if (g.force_full || !g.fast_ok || !sf_fast_w_supported(W)) {
     HIPCHK(hipEventRecord(e0, st));
-    rc = launch_full(d_seqs, nullptr, nullptr, n, 1, 1, W, d_out, nullptr, st);
+    rc = launch_full(d_seqs, nullptr, nullptr, n, 1, 1, W, d_out, d_db, d_db ? trace_stride : 0, st);
     HIPCHK(hipEventRecord(e1, st));
   } else {
+    if ((rc = ensure(g.status, sizeof(int)))) return rc;
     rc = ensure(g.ovf, sizeof(int) * ((size_t)n + 1));
     if (rc) return rc;
     int *d_cnt = (int *)g.ovf.p, *d_list = d_cnt + 1;
@@ -206,11 +209,11 @@ int launch_mfe(const uint8_t *d_seqs, int n, int W, int32_t *d_out, hipStream_t 
     if (rc) return rc;
     HIPCHK(hipEventRecord(e0, st));
     sf_fast_launch(grid, threads, lds, st, d_seqs, n, W, (const SfDevParams *)g.dP, (const SfFastParams *)g.dF,
-                   (int16_t *)g.fast_scratch.p, d_out, d_cnt, d_list);
+                   (int16_t *)g.fast_scratch.p, d_out, d_cnt, d_list, trace_stride, d_db, (int *)g.status.p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(e1, st));
     // folds that left the int16 range are redone exactly
-    rc = launch_full(d_seqs, d_list, d_cnt, n, 1, 1, W, d_out, nullptr, st);
+    rc = launch_full(d_seqs, d_list, d_cnt, n, 1, 1, W, d_out, d_db, d_db ? trace_stride : 0, st);
   }
   g.ev.push_back({e0, e1});
   g.prof_launches++;
@@ -350,8 +353,7 @@ int sf_mfe_trace_batch(const uint8_t *seqs, int n, int W, int32_t *mfe_out, char
   if ((rc = ensure(g.status, sizeof(int)))) return rc;
   HIPCHK(hipMemsetAsync(g.status.p, 0, sizeof(int), g.stream));
   HIPCHK(hipMemcpyAsync(g.seqs.p, seqs, (size_t)n * W, hipMemcpyHostToDevice, g.stream));
-  if ((rc = launch_full((const uint8_t *)g.seqs.p, nullptr, nullptr, n, 1, 1, W, (int32_t *)g.energies.p,
-                        (char *)g.db.p, g.stream)))
+  if ((rc = launch_mfe((const uint8_t *)g.seqs.p, n, W, (int32_t *)g.energies.p, g.stream, 1, (char *)g.db.p)))
     return rc;
   int st = 0;
   if (mfe_out)
@@ -437,12 +439,9 @@ int sf_scan_dev(const uint8_t *d_tr, int L, int W, int step, int win_begin, int 
   for (int w0 = 0; w0 < n_win; w0 += chunk) {
     const int nw = (n_win - w0 < chunk) ? n_win - w0 : chunk;
     if ((rc = launch_shuffle(d_tr, L, W, step, win_begin + w0, nw, r, kind, seed, d_seqs, st))) return rc;
-    if ((rc = launch_mfe(d_seqs, nw * (r + 1), W, d_energies + (size_t)w0 * (r + 1), st))) return rc;
-    if (!(flags & SF_SCAN_NO_TRACE) && d_structure) {
-      // native rows only (row stride r+1); the energy is NOT rewritten: structure string only
-      if ((rc = launch_full(d_seqs, nullptr, nullptr, nw, r + 1, 0, W, nullptr, d_structure + (size_t)w0 * (W + 1), st)))
-        return rc;
-    }
+    char *dbp = (!(flags & SF_SCAN_NO_TRACE) && d_structure) ? d_structure + (size_t)w0 * (W + 1) : nullptr;
+    // r+1 energies per window; the native row (every (r+1)-th) also gets its structure in the same launch
+    if ((rc = launch_mfe(d_seqs, nw * (r + 1), W, d_energies + (size_t)w0 * (r + 1), st, r + 1, dbp))) return rc;
     if (!(flags & SF_SCAN_NO_PF)) {
       if ((rc = launch_pf(d_seqs, nw, r + 1, W, d_ens_dG ? d_ens_dG + w0 : nullptr, d_ens_div ? d_ens_div + w0 : nullptr,
                           d_centroid ? d_centroid + (size_t)w0 * (W + 1) : nullptr, nullptr, st)))

@@ -8,4 +8,11 @@
 #define SF_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
 #define SF_LAUNCH(kern, grid, block, shmem, stream, ...) \
   hipLaunchKernelGGL(kern, dim3(grid), dim3(block), shmem, stream, __VA_ARGS__)
+// lanes of one wave exchanging data through LDS: keep the compiler from moving LDS accesses across this point
+#define SF_WAVE_SYNC()                                  \
+  do {                                                  \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+    __builtin_amdgcn_wave_barrier();                    \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+  } while (0)
 #endif

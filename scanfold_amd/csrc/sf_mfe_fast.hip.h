@@ -143,19 +143,32 @@ struct SfFastCtx {
   const SfFastParams *F;
   int16_t *cg;
   int W, TAU, MLbase, MLclosing, MLintern;
+  int vNIN, vIL, vL1N, vBUL;  // lane k of the wave holds table entry k (see SF_UNI)
 };
 
 #define SF_TIDX(t, a, b) ((t)*25 + (a)*5 + (b))
 
+// Size-dependent terms (loop initiation, asymmetry) are the same for every lane.  Each wave keeps the four
+// tables spread over the lanes of four VGPRs (lane k holds entry k) and fetches entry k with v_readlane:
+// no memory access and no wait in the unrolled candidate code.
+#ifdef SF_EMUL
+#define SF_UNI(vreg, table, k) ((table)[k])
+#else
+#define SF_UNI(vreg, table, k) __builtin_amdgcn_readlane((vreg), (k))
+#endif
+
 // One anti-diagonal for one thread.  H: this parity's per-size minima of the generic candidates of the
 // enclosed cell (i+1, j-1) on entry, of (i, j) on exit.  slot2 = (d-2) mod NR, slotd = d mod NR.
+// G ("guarded"): d < 36, the loop-size limit d-6 is below MAXLOOP and every size is tested against it;
+// !G: all sizes 0..30 exist, the candidate code is one straight-line block the scheduler can pipeline.
+template <bool G>
 __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, const int i, const bool valid,
                                              const int slot2, const int slotd, int (&H)[27], int &ovf) {
   const int W = X.W;
   if (!valid) return;
   const int j = i + d, i0 = i - 1;
   const uint8_t *S = X.S;
-  const int umax = sfd_min(SFD_MAXLOOP, d - 2 - (SFD_TURN + 1));
+  const int umax = G ? sfd_min(SFD_MAXLOOP, d - 2 - (SFD_TURN + 1)) : SFD_MAXLOOP;
   const int type = X.tPair[S[i] * 8 + S[j]];
   const int si1 = S[i + 1], sj1 = S[j - 1];
 // fML triangle without diagonals 0..3: base(d) = sum_{k=4}^{d-1} (W-k)
@@ -164,19 +177,21 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
 #define ROW(u) ((slot2 - (u) < 0 ? slot2 - (u) + SF_FAST_NR : slot2 - (u)) * W)
 
   // ---- pass 1 (every cell): per-size minima of the generic interior candidates ----
+#ifndef SF_ABL_PASS1
 #pragma unroll
   for (int u = 30; u >= 6; --u) {
-    if (u <= umax) {
+    if (!G || u <= umax) {
       const int16_t *row = X.CI + ROW(u) + i0;
-      const int e = sfd_min(row[3], row[u - 1]) + X.F->NIN[u - 4];  // u1 = 2 and u2 = 2
+      const int e = sfd_min(row[3], row[u - 1]) + SF_UNI(X.vNIN, X.F->NIN, u - 4);  // u1 = 2 and u2 = 2
       H[u - 4] = sfd_min(e, H[u - 6]);
     }
   }
-  if (umax >= 5) {
+  if (!G || umax >= 5) {
     const int16_t *row = X.CI + ROW(5) + i0;
-    H[1] = sfd_min(row[3], row[4]) + X.F->NIN[1];
+    H[1] = sfd_min(row[3], row[4]) + SF_UNI(X.vNIN, X.F->NIN, 1);
   }
-  if (umax >= 4) H[0] = X.CI[ROW(4) + i0 + 3] + X.F->NIN[0];
+  if (!G || umax >= 4) H[0] = X.CI[ROW(4) + i0 + 3] + SF_UNI(X.vNIN, X.F->NIN, 0);
+#endif
 
   // ---- pass 2 (pairable cells): c[i,j] ----
   int c = SF_INF16;
@@ -184,39 +199,40 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
     const int TAU = X.TAU;
     const sf_params_blob &P = X.D->P;
     int e;
-    if (d <= 7) e = sfd_hairpin(X.D, S, i, j, type);  // sizes 3, 4, 6 may be special loops
+    if (G && d <= 7) e = sfd_hairpin(X.D, S, i, j, type);  // sizes 3, 4, 6 may be special loops
     else e = X.D->hp_init[d - 1] + X.tH[SF_TIDX(type, si1, sj1)];
-    if (umax >= 0) {
+    if (!G || umax >= 0) {
       const int tau_out = type > 2 ? TAU : 0;
       const int16_t *st = X.tStack + type * 8;
+#ifndef SF_ABL_RARE
       {  // stack
         const int t2r = sfd_rtype(X.tPair[si1 * 8 + sj1]);
         e = sfd_min(e, X.CB[ROW(0) + i0 + 1] - (t2r > 2 ? TAU : 0) + st[t2r]);
       }
-      if (umax >= 1) {  // one-nucleotide bulges keep the stack
-        const int b1 = X.F->BUL[1];
+      if (!G || umax >= 1) {  // one-nucleotide bulges keep the stack
+        const int b1 = SF_UNI(X.vBUL, X.F->BUL, 1);
         const int16_t *row = X.CB + ROW(1) + i0;
         const int ta = sfd_rtype(X.tPair[si1 * 8 + S[j - 2]]);  // (i+1, j-2)
         e = sfd_min(e, row[1] - (ta > 2 ? TAU : 0) + b1 + st[ta]);
         const int tb = sfd_rtype(X.tPair[S[i + 2] * 8 + sj1]);  // (i+2, j-1)
         e = sfd_min(e, row[2] - (tb > 2 ? TAU : 0) + b1 + st[tb]);
       }
-      if (umax >= 2) {  // 1 x 1: (i+2, j-2)
+      if (!G || umax >= 2) {  // 1 x 1: (i+2, j-2)
         const int t2r = sfd_rtype(X.tPair[S[i + 2] * 8 + S[j - 2]]);
         e = sfd_min(e, X.CB[ROW(2) + i0 + 2] - (t2r > 2 ? TAU : 0) + P.int11[type][t2r][si1][sj1]);
       }
-      if (umax >= 3) {  // 1 x 2 and 2 x 1
+      if (!G || umax >= 3) {  // 1 x 2 and 2 x 1
         const int16_t *row = X.CB + ROW(3) + i0;
         const int ta = sfd_rtype(X.tPair[S[i + 2] * 8 + S[j - 3]]);  // (i+2, j-3), sq1 = S[j-2]
         e = sfd_min(e, row[2] - (ta > 2 ? TAU : 0) + P.int21[type][ta][si1][S[j - 2]][sj1]);
         const int tb = sfd_rtype(X.tPair[S[i + 3] * 8 + S[j - 2]]);  // (i+3, j-2), sp1 = S[i+2]
         e = sfd_min(e, row[3] - (tb > 2 ? TAU : 0) + P.int21[tb][type][sj1][si1][S[i + 2]]);
       }
-      if (umax >= 4) {  // 2 x 2: (i+3, j-3)
+      if (!G || umax >= 4) {  // 2 x 2: (i+3, j-3)
         const int t2r = sfd_rtype(X.tPair[S[i + 3] * 8 + S[j - 3]]);
         e = sfd_min(e, X.CB[ROW(4) + i0 + 3] - (t2r > 2 ? TAU : 0) + P.int22[type][t2r][si1][S[i + 2]][S[j - 2]][sj1]);
       }
-      if (umax >= 5) {  // 2 x 3 and 3 x 2
+      if (!G || umax >= 5) {  // 2 x 3 and 3 x 2
         const int16_t *row = X.CB + ROW(5) + i0;
         const int m23 = X.t23[SF_TIDX(type, si1, sj1)] + X.F->L23;
         const int ta = sfd_rtype(X.tPair[S[i + 3] * 8 + S[j - 4]]);  // (i+3, j-4); sp1 = S[i+2], sq1 = S[j-3]
@@ -224,17 +240,20 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
         const int tb = sfd_rtype(X.tPair[S[i + 4] * 8 + S[j - 3]]);  // (i+4, j-3); sp1 = S[i+3], sq1 = S[j-2]
         e = sfd_min(e, row[4] - (tb > 2 ? TAU : 0) + m23 + X.t23[SF_TIDX(tb, S[j - 2], S[i + 3])]);
       }
+#endif
       // bulges (size u >= 2), 1 x n loops (total size u >= 4) and the generic minima, one rolling row per u
       int gb = SF_FAST_BIG, g1 = SF_FAST_BIG, gg = SF_FAST_BIG;
+#ifndef SF_ABL_PASS2
 #pragma unroll
       for (int u = 2; u <= 30; ++u) {
-        if (u <= umax) {
+        if (!G || u <= umax) {
           const int rw = ROW(u) + i0;
-          gb = sfd_min(gb, sfd_min(X.CB[rw + 1], X.CB[rw + 1 + u]) + X.F->BUL[u]);
-          if (u >= 4) g1 = sfd_min(g1, sfd_min(X.C1N[rw + 2], X.C1N[rw + u]) + X.F->L1N[u - 1]);
-          if (u >= 6) gg = sfd_min(gg, H[u - 4] + X.F->IL[u]);
+          gb = sfd_min(gb, sfd_min(X.CB[rw + 1], X.CB[rw + 1 + u]) + SF_UNI(X.vBUL, X.F->BUL, u));
+          if (u >= 4) g1 = sfd_min(g1, sfd_min(X.C1N[rw + 2], X.C1N[rw + u]) + SF_UNI(X.vL1N, X.F->L1N, u - 1));
+          if (u >= 6) gg = sfd_min(gg, H[u - 4] + SF_UNI(X.vIL, X.F->IL, u));
         }
       }
+#endif
       e = sfd_min(e, gb + tau_out);
       e = sfd_min(e, g1 + X.t1n[SF_TIDX(type, si1, sj1)]);
       e = sfd_min(e, gg + X.tI[SF_TIDX(type, si1, sj1)]);
@@ -268,19 +287,47 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
   } else {
     X.CI[rbd] = SF_INF16; X.C1N[rbd] = SF_INF16; X.CB[rbd] = SF_INF16;
   }
-  X.cg[d * W + i0] = (int16_t)c;
+  X.cg[(j - 1) * W + i0] = (int16_t)c;  // row j, column i: the exterior pass reads rows coalesced
   // fML[i,j]
   if (d > SFD_TURN + 1) {
     const int fb = FBASE(d - 1);
     f = sfd_min(f, sfd_min(X.fML[fb + i0 + 1], X.fML[fb + i0]) + X.MLbase);
   }
   int dec = SF_FAST_BIG;
+#ifndef SF_ABL_DML
   {
-    const int16_t *fa = X.fML + i0;       // fML[i, i+m]   = fa[FBASE(m)]
-    const int16_t *fb2 = X.fML + i0 + 1;  // fML[i+m+1, j] = fb2[FBASE(d-m-1) + m]
-#pragma unroll 4
-    for (int m = SFD_TURN + 1; m <= d - SFD_TURN - 2; m++) dec = sfd_min(dec, fa[FBASE(m)] + fb2[FBASE(d - m - 1) + m]);
+    // fML[i, i+m] = fML_tri[FBASE(m) + i0], fML[i+m+1, j] = fML_tri[FBASE(d-m-1) + i0+m+1]; both offsets are
+    // wave-uniform and advance by simple differences: FBASE(m+1)-FBASE(m) = W-m
+    const int16_t *fa = X.fML + i0;
+    const int16_t *fb2 = X.fML + i0 + 1;
+    int ia = 0;                                             // FBASE(4)
+    int ib = FBASE(d - SFD_TURN - 2) + SFD_TURN + 1;        // FBASE(d-m-1) + m at m = 4
+    int m = SFD_TURN + 1;
+    const int mend = d - SFD_TURN - 2;
+    int dec2 = SF_FAST_BIG;
+    for (; m + 7 <= mend; m += 8) {
+      int a[8], b[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        a[k] = fa[ia];
+        b[k] = fb2[ib];
+        ia += W - (m + k);
+        ib -= W - d + (m + k) + 1;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; k += 2) {
+        dec = sfd_min(dec, a[k] + b[k]);
+        dec2 = sfd_min(dec2, a[k + 1] + b[k + 1]);
+      }
+    }
+    for (; m <= mend; m++) {
+      dec = sfd_min(dec, fa[ia] + fb2[ib]);
+      ia += W - m;
+      ib -= W - d + m + 1;
+    }
+    dec = sfd_min(dec, dec2);
   }
+#endif
   f = sfd_min(f, dec);
   if (f < SF_FAST_OVF) ovf = 1;
   X.DMLr[(d % 3) * W + i0] = (int16_t)(dec > SF_FAST_THRESH ? SF_INF16 : dec);
@@ -288,12 +335,150 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
 #undef ROW
 }
 
+// Wave-cooperative traceback over the tables the fill left behind (fML triangle in LDS, c in device memory,
+// f5 in LDS).  Same order of alternatives as sf_mfe_full_kernel / the oracle; candidate
+// tests are spread over the 64 lanes and the first hit in that order is taken with ballot + ffs.
+// Every lane executes the same control flow on the same values, so stack and string writes are redundant
+// identical stores.  Returns nonzero if some table value has no decomposition.
+__device__ inline int sf_fast_traceback(const SfFastCtx &X, const int32_t *f5s, const int16_t *tExt, const int lane,
+                                        int16_t *stI, int16_t *stJ, int16_t *stM, char *dbL) {
+  const int W = X.W;
+  const uint8_t *S = X.S;
+  const SfDevParams *D = X.D;
+#define TC(i, j) ((int)X.cg[((j)-1) * W + (i)-1])
+#define TF(i, j) (((j) - (i) < SFD_TURN + 1) ? SF_INF16 : (int)X.fML[FBASE((j) - (i)) + (i)-1])
+#define TPAIR(i, j) ((int)X.tPair[S[i] * 8 + S[j]])
+  for (int x = lane; x < W; x += 64) dbL[x] = '.';
+  int sp = 0, bad = 0;
+  stI[0] = 1; stJ[0] = (int16_t)W; stM[0] = 0; sp = 1;
+  while (sp > 0 && !bad) {
+    --sp;
+    int i = stI[sp], j = stJ[sp];
+    const int ml = stM[sp];
+    bool have_pair = false;
+    if (ml == 0) {
+      while (j > 0 && f5s[j] == f5s[j - 1]) j--;
+      if (j < SFD_TURN + 2) continue;
+      const int fij = f5s[j];
+      int found = -1;
+      for (int base = j - SFD_TURN - 1; base >= 1 && found < 0; base -= 64) {
+        const int k = base - lane;
+        bool ok = false;
+        if (k >= 1) {
+          const int type = TPAIR(k, j);
+          if (type) {
+            int ext;
+            if (k > 1 && j < W) ext = tExt[SF_TIDX(type, S[k - 1], S[j + 1])];
+            else if (k > 1) ext = X.tD5[type * 5 + S[k - 1]];
+            else if (j < W) ext = X.tD3[type * 5 + S[j + 1]];
+            else ext = 0;
+            ok = (fij == f5s[k - 1] + TC(k, j) + ext + (type > 2 ? X.TAU : 0));
+          }
+        }
+        const unsigned long long m = __ballot(ok);
+        if (m) found = base - (__ffsll(m) - 1);
+      }
+      if (found < 0) { bad = 1; break; }
+      stI[sp] = 1; stJ[sp] = (int16_t)(found - 1); stM[sp] = 0; sp++;
+      i = found;
+      have_pair = true;
+    } else {
+      if (j - i < SFD_TURN + 1) { bad = 1; break; }
+      while (j - i > SFD_TURN + 1 && TF(i, j - 1) < SF_INF16 && TF(i, j) == TF(i, j - 1) + X.MLbase) j--;
+      while (j - i > SFD_TURN + 1 && TF(i + 1, j) < SF_INF16 && TF(i, j) == TF(i + 1, j) + X.MLbase) i++;
+      const int fij = TF(i, j);
+      const int type = TPAIR(i, j);
+      int stem = 0;
+      if (type) {
+        if (i > 1 && j < W) stem = X.tM[SF_TIDX(type, S[i - 1], S[j + 1])];
+        else if (i > 1) stem = X.tD5[type * 5 + S[i - 1]];
+        else if (j < W) stem = X.tD3[type * 5 + S[j + 1]];
+        stem += (type > 2 ? X.TAU : 0) + X.MLintern;
+      }
+      if (type && fij == TC(i, j) + stem) {
+        have_pair = true;
+      } else {
+        int found = -1;
+        for (int base = i + SFD_TURN + 1; base <= j - SFD_TURN - 2 && found < 0; base += 64) {
+          const int k = base + lane;
+          bool ok = false;
+          if (k <= j - SFD_TURN - 2) {
+            const int a = TF(i, k), b = TF(k + 1, j);
+            ok = a < SF_INF16 && b < SF_INF16 && fij == a + b;
+          }
+          const unsigned long long m = __ballot(ok);
+          if (m) found = base + (__ffsll(m) - 1);
+        }
+        if (found < 0) { bad = 1; break; }
+        stI[sp] = (int16_t)i; stJ[sp] = (int16_t)found; stM[sp] = 1; sp++;
+        stI[sp] = (int16_t)(found + 1); stJ[sp] = (int16_t)j; stM[sp] = 1; sp++;
+      }
+    }
+    while (have_pair) {
+      dbL[i - 1] = '(';
+      dbL[j - 1] = ')';
+      const int type = TPAIR(i, j);
+      const int cij = TC(i, j);
+      if (cij == sfd_hairpin(D, S, i, j, type)) break;
+      const int d = j - i;
+      const int umax = sfd_min(SFD_MAXLOOP, d - 2 - (SFD_TURN + 1));
+      int found = -1;
+      if (umax >= 0) {
+        // candidates in the order u1 ascending (p ascending), u2 ascending (q descending): t = u1*31 + u2
+        const int tmax = umax * 31 + umax;
+        for (int base = 0; base <= tmax && found < 0; base += 64) {
+          const int t = base + lane;
+          const int u1 = t / 31, u2 = t - u1 * 31;
+          bool ok = false;
+          if (u1 + u2 <= umax) {
+            const int p = i + 1 + u1, q = j - 1 - u2;
+            const int t2 = TPAIR(p, q);
+            if (t2)
+              ok = (cij == sfd_intloop(D, u1, u2, type, sfd_rtype(t2), S[i + 1], S[j - 1], S[p - 1], S[q + 1]) + TC(p, q));
+          }
+          const unsigned long long m = __ballot(ok);
+          if (m) found = base + (__ffsll(m) - 1);
+        }
+      }
+      if (found >= 0) {
+        const int u1 = found / 31, u2 = found - u1 * 31;
+        i = i + 1 + u1;
+        j = j - 1 - u2;
+        continue;
+      }
+      const int tr = sfd_rtype(type);
+      const int mm = X.MLclosing + X.tM[SF_TIDX(tr, S[j - 1], S[i + 1])] + (tr > 2 ? X.TAU : 0) + X.MLintern;
+      int fk = -1;
+      for (int base = i + 1 + SFD_TURN + 1; base <= j - 1 - SFD_TURN - 2 && fk < 0; base += 64) {
+        const int k = base + lane;
+        bool ok = false;
+        if (k <= j - 1 - SFD_TURN - 2) {
+          const int a = TF(i + 1, k), b = TF(k + 1, j - 1);
+          ok = a < SF_INF16 && b < SF_INF16 && cij == a + b + mm;
+        }
+        const unsigned long long m = __ballot(ok);
+        if (m) fk = base + (__ffsll(m) - 1);
+      }
+      if (fk < 0) { bad = 1; break; }
+      stI[sp] = (int16_t)(i + 1); stJ[sp] = (int16_t)fk; stM[sp] = 1; sp++;
+      stI[sp] = (int16_t)(fk + 1); stJ[sp] = (int16_t)(j - 1); stM[sp] = 1; sp++;
+      break;
+    }
+  }
+#undef TC
+#undef TF
+#undef TPAIR
+  return bad;
+}
+
 template <int NT>
 __global__ __launch_bounds__(NT) void sf_mfe_fast_kernel(const uint8_t *__restrict__ seqs, int n, int W,
                                                          const SfDevParams *__restrict__ D,
                                                          const SfFastParams *__restrict__ F,
                                                          int16_t *__restrict__ cg_all, int32_t *__restrict__ out,
-                                                         int *__restrict__ ovf_cnt, int *__restrict__ ovf_list) {
+                                                         int *__restrict__ ovf_cnt, int *__restrict__ ovf_list,
+                                                         int trace_stride, char *__restrict__ db_out,
+                                                         int *__restrict__ status) {
   SF_DYN_SMEM(smem);
   const SfFastLayout Lo = sf_fast_layout(W);
   SfFastCtx X;
@@ -307,7 +492,7 @@ __global__ __launch_bounds__(NT) void sf_mfe_fast_kernel(const uint8_t *__restri
   X.tStack = tab + 1000; X.tD5 = tab + 1064; X.tD3 = tab + 1104;
   uint8_t *tPair = (uint8_t *)(tab + 1144);
   X.tPair = tPair;
-  int32_t *red = (int32_t *)(smem + Lo.off_red);
+  (void)Lo.off_red;
   int32_t *flag = (int32_t *)(smem + Lo.off_flag);
   uint8_t *S = (uint8_t *)(smem + Lo.off_S);
   X.S = S;
@@ -327,6 +512,10 @@ __global__ __launch_bounds__(NT) void sf_mfe_fast_kernel(const uint8_t *__restri
   for (int x = tid; x < 64; x += NT) { tab[1000 + x] = F->stack[x]; tPair[x] = F->pair[x]; }
   for (int x = tid; x < 40; x += NT) { tab[1064 + x] = F->d5[x]; tab[1104 + x] = F->d3[x]; }
 
+  {
+    const int lk = tid & 31;
+    X.vNIN = F->NIN[lk]; X.vIL = F->IL[lk]; X.vL1N = F->L1N[lk]; X.vBUL = F->BUL[lk];
+  }
   // centre-based thread mapping: v = (tid + OFF) mod NT, cell i = v - d/2
   const int OFF = (NT > 64) ? (((W + 1) >> 1) - 32 + NT) & (NT - 1) : 0;
   const int v = (tid + OFF) & (NT - 1);
@@ -348,7 +537,14 @@ __global__ __launch_bounds__(NT) void sf_mfe_fast_kernel(const uint8_t *__restri
       {
         const int i = v - (d >> 1);
         const bool valid = (i >= 1) && (i + d <= W);
-        if (__ballot(valid)) sf_fast_cell(X, d, i, valid, slot2, slotd, Ha, ovf);
+#ifdef SF_ABL_CELL
+        if (0) {
+#else
+        if (__ballot(valid)) {
+#endif
+          if (d < SFD_MAXLOOP + 6) sf_fast_cell<true>(X, d, i, valid, slot2, slotd, Ha, ovf);
+          else sf_fast_cell<false>(X, d, i, valid, slot2, slotd, Ha, ovf);
+        }
       }
       __syncthreads();
       slot2 = slot2 + 1 == SF_FAST_NR ? 0 : slot2 + 1;
@@ -357,42 +553,92 @@ __global__ __launch_bounds__(NT) void sf_mfe_fast_kernel(const uint8_t *__restri
         const int d1 = d + 1;
         const int i = v - (d1 >> 1);
         const bool valid = (i >= 1) && (i + d1 <= W);
-        if (__ballot(valid)) sf_fast_cell(X, d1, i, valid, slot2, slotd, Hb, ovf);
+#ifdef SF_ABL_CELL
+        if (0) {
+#else
+        if (__ballot(valid)) {
+#endif
+          if (d1 < SFD_MAXLOOP + 6) sf_fast_cell<true>(X, d1, i, valid, slot2, slotd, Hb, ovf);
+          else sf_fast_cell<false>(X, d1, i, valid, slot2, slotd, Hb, ovf);
+        }
       }
       __syncthreads();
       slot2 = slot2 + 1 == SF_FAST_NR ? 0 : slot2 + 1;
       slotd = slotd + 1 == SF_FAST_NR ? 0 : slotd + 1;
     }
 
-    // exterior loop (same recurrence as sf_mfe_full_kernel); thread t handles i = t+1 here.
-    // A thread reads c values other threads wrote to device memory: the barriers above order them.
+    // ---- exterior loop f5[j] = min(f5[j-1], min_i f5[i-1] + c[i,j] + ExtLoop(i,j)) : wave 0 only ----
+    // lane l owns i = l+1, l+65, ...; f5[i-1] sits in its registers, c rows stream from device memory
+    // (one row ahead), the minimum over i is a wave butterfly.  No workgroup barrier inside the loop.
     if (ovf) flag[0] = 1;
     for (int x = tid; x < 200; x += NT) tExt[x] = F->mmExt[x];
-    if (tid == 0) f5s[0] = 0;
     __syncthreads();
-    for (int j = 1; j <= W; j++) {
-      int val = SF_FAST_BIG * 2;
-      const int i = tid + 1;
-      if (i + SFD_TURN + 1 <= j) {
-        const int type = tPair[S[i] * 8 + S[j]];
-        if (type) {
-          int ext;
-          if (i > 1 && j < W) ext = tExt[SF_TIDX(type, S[i - 1], S[j + 1])];
-          else if (i > 1) ext = X.tD5[type * 5 + S[i - 1]];
-          else if (j < W) ext = X.tD3[type * 5 + S[j + 1]];
-          else ext = 0;
-          val = f5s[i - 1] + X.cg[(j - i) * W + i - 1] + ext + (type > 2 ? X.TAU : 0);
+    if (tid < 64) {
+      constexpr int NQ = NT / 64;
+      const int lane = tid;
+      int f5r[NQ], cn[NQ], si[NQ], sim1[NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; q++) {
+        const int i = lane + 64 * q + 1;
+        f5r[q] = 0;
+        si[q] = i <= W ? S[i] : 0;
+        sim1[q] = i <= W ? S[i - 1] : 0;
+        cn[q] = i <= W ? X.cg[i - 1] : SF_INF16;
+      }
+      int f5prev = 0;
+      if (lane == 0) f5s[0] = 0;
+#ifdef SF_ABL_F5
+      for (int j = W; j <= W; j++) {
+#else
+      for (int j = 1; j <= W; j++) {
+#endif
+        int cc[NQ];
+        const int sj = S[j], sj1 = S[j + 1];
+        int val = SF_FAST_BIG * 2;
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+          const int i = lane + 64 * q + 1;
+          cc[q] = cn[q];
+          if (j < W && i <= W) cn[q] = X.cg[j * W + i - 1];
+          if (i + SFD_TURN + 1 <= j) {
+            const int type = tPair[si[q] * 8 + sj];
+            if (type) {
+              int ext;
+              if (i > 1 && j < W) ext = tExt[SF_TIDX(type, sim1[q], sj1)];
+              else if (i > 1) ext = X.tD5[type * 5 + sim1[q]];
+              else if (j < W) ext = X.tD3[type * 5 + sj1];
+              else ext = 0;
+              val = sfd_min(val, f5r[q] + cc[q] + ext + (type > 2 ? X.TAU : 0));
+            }
+          }
+        }
+        for (int m = 32; m >= 1; m >>= 1) val = sfd_min(val, __shfl_xor(val, m));
+        const int f5j = sfd_min(f5prev, val);
+        f5prev = f5j;
+        if (lane == 0) f5s[j] = f5j;
+#pragma unroll
+        for (int q = 0; q < NQ; q++)
+          if (lane + 64 * q == j) f5r[q] = f5j;
+      }
+      SF_WAVE_SYNC();  // f5s[] was written by lane 0, the traceback reads it from every lane
+      const int over = flag[0] || f5prev < SF_FAST_OVF;
+      if (lane == 0) {
+        out[seq] = f5prev;
+        if (over) {
+          const int k = atomicAdd(ovf_cnt, 1);
+          ovf_list[k] = seq;
         }
       }
-      val = sf_block_min(val, red);
-      if (tid == 0) f5s[j] = sfd_min(f5s[j - 1], val);
-      __syncthreads();
-    }
-    if (tid == 0) {
-      out[seq] = f5s[W];
-      if (flag[0] || f5s[W] < SF_FAST_OVF) {
-        const int k = atomicAdd(ovf_cnt, 1);
-        ovf_list[k] = seq;
+      // ---- traceback for the sequences whose structure is wanted (native windows) ----
+      if (db_out && !over && (seq % trace_stride) == 0) {
+        int16_t *stI = (int16_t *)(smem + Lo.off_c1n);
+        int16_t *stJ = stI + W + 8;
+        int16_t *stM = stJ + W + 8;
+        char *dbL = (char *)(smem + Lo.off_cb);
+        const int bad = sf_fast_traceback(X, f5s, tExt, lane, stI, stJ, stM, dbL);
+        char *dst = db_out + (size_t)(seq / trace_stride) * (W + 1);
+        for (int x = lane; x <= W; x += 64) dst[x] = x < W ? dbL[x] : 0;
+        if (bad && lane == 0) atomicOr(status, 1);
       }
     }
   }

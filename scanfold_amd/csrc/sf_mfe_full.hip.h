@@ -26,11 +26,13 @@ __device__ inline int sf_block_min(int v, int *red) {
 }
 
 // items: k in [0, n_items); sequence row = idx_list ? idx_list[k] : k*row_stride;
-// energy goes to mfe_out[idx_list ? idx_list[k] : k*mfe_stride] (if mfe_out), structure to db_out + k*(W+1).
+// energy goes to mfe_out[idx_list ? idx_list[k] : k*mfe_stride] (if mfe_out); structure (if db_out) goes to
+// db_out + k*(W+1) when db_stride == 0, else only rows that are multiples of db_stride are traced, into
+// db_out + (row/db_stride)*(W+1) (how the fast kernel's overflow list maps back to native windows).
 __global__ void sf_mfe_full_kernel(const uint8_t *__restrict__ seqs, const int *__restrict__ idx_list,
                                    const int *__restrict__ count_ptr, int n, int row_stride, int mfe_stride, int W,
                                    const SfDevParams *__restrict__ D, int32_t *__restrict__ scratch,
-                                   int32_t *__restrict__ mfe_out, char *__restrict__ db_out,
+                                   int32_t *__restrict__ mfe_out, char *__restrict__ db_out, int db_stride,
                                    int *__restrict__ status) {
   __shared__ uint8_t S[SF_MAX_W + 2];
   __shared__ int f5s[SF_MAX_W + 1];
@@ -109,8 +111,8 @@ __global__ void sf_mfe_full_kernel(const uint8_t *__restrict__ seqs, const int *
     }
     if (tid == 0 && mfe_out) mfe_out[idx_list ? idx_list[k] : k * mfe_stride] = f5s[W];
 
-    if (db_out && tid == 0) {
-      char *db = db_out + (size_t)k * W1;
+    if (db_out && tid == 0 && (db_stride == 0 || row % db_stride == 0)) {
+      char *db = db_out + (size_t)(db_stride ? row / db_stride : k) * W1;
       for (int x = 0; x < W; x++) db[x] = '.';
       db[W] = 0;
       int s = 0, bad = 0;

@@ -153,6 +153,8 @@ inline T atomicMin(T *p, T v) { T o = *p; if (v < o) *p = v; return o; }
 template <typename T>
 inline T atomicOr(T *p, T v) { T o = *p; *p = o | v; return o; }
 
+#define SF_WAVE_SYNC() sfemul::wave_barrier()
+
 /* dynamic shared memory */
 #define SF_DYN_SMEM(name) char *name = sfemul::g_blk->smem.data()
 

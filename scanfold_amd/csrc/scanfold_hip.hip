@@ -15,6 +15,7 @@
 #include "sf_mfe_full.hip.h"
 #include "sf_mfe_fast.hip.h"
 #include "sf_pf.hip.h"
+#include "sf_pf_fast.hip.h"
 #include "sf_shuffle.hip.h"
 
 namespace {
@@ -175,10 +176,17 @@ int launch_pf(const uint8_t *d_seqs, int n, int row_stride, int W, double *d_dG,
               double *d_cd, hipStream_t st) {
   if (n <= 0) return SF_OK;
   int grid = n < max_resident_blocks() ? n : max_resident_blocks();
-  int rc = ensure(g.pf_scratch, (size_t)grid * SF_PF_SCRATCH_DOUBLES(W) * sizeof(double));
-  if (rc) return rc;
-  SF_LAUNCH(sf_pf_kernel, grid, block_threads(W), 0, st, d_seqs, n, row_stride, W, (const SfDevParams *)g.dP,
-            (const SfDevParamsPF *)g.dX, (double *)g.pf_scratch.p, d_dG, d_mbd, d_cen, d_cd);
+  if (W >= 16 && W <= SF_PFF_MAXW && !g.force_full) {
+    int rc = ensure(g.pf_scratch, (size_t)grid * SF_PFF_SCRATCH_DOUBLES(W) * sizeof(double));
+    if (rc) return rc;
+    sf_pf_fast_launch(grid, W, st, d_seqs, n, row_stride, W, (const SfDevParams *)g.dP, (const SfDevParamsPF *)g.dX,
+                      (double *)g.pf_scratch.p, d_dG, d_mbd, d_cen, d_cd);
+  } else {
+    int rc = ensure(g.pf_scratch, (size_t)grid * SF_PF_SCRATCH_DOUBLES(W) * sizeof(double));
+    if (rc) return rc;
+    SF_LAUNCH(sf_pf_kernel, grid, block_threads(W), 0, st, d_seqs, n, row_stride, W, (const SfDevParams *)g.dP,
+              (const SfDevParamsPF *)g.dX, (double *)g.pf_scratch.p, d_dG, d_mbd, d_cen, d_cd);
+  }
   HIPCHK(hipGetLastError());
   return SF_OK;
 }

@@ -1,0 +1,335 @@
+// sf_pf_fast.hip.h — McCaskill partition function for W <= 256 with O(MAXLOOP) interior-loop work per cell.
+//
+// Same mathematics and outputs as sf_pf.hip.h (which stays as the W > 256 path); replaces fc.pf() /
+// fc.centroid() / fc.mean_bp_distance() for the native windows (ScanFold-Scan.py:383-389).  Differences:
+//  * centre-based thread mapping (see sf_mfe_fast.hip.h): the cell a thread handles two diagonals later
+//    encloses the current one, so the generic interior-loop SUM is carried in registers:
+//      inside   H[i,j,u] = sum_{u1+u2=u; u1,u2>=2} qbI[i+1+u1, j-1-u2] w(|u1-u2|) = H[i+1,j-1,u-2] + 2 edge terms
+//      outside  G[i,j,u] = sum_{u1+u2=u; u1,u2>=2} obI[i-1-u1, j+1+u2] w(|u1-u2|) = G[i-1,j+1,u-2] + 2 edge terms
+//    (qbI / obI = qb / ob pre-multiplied by the pair's own interior mismatch weight), 6 table reads per loop
+//    size instead of one per (u1,u2);
+//  * every O(W) multiloop sum is indexed by diagonal so that the threads of a wave read consecutive addresses.
+// Tables are FP64, diagonal-major T(d,i), in device memory (L2-resident: 13 tables x W x (W+1) doubles per
+// workgroup).  Sums are re-associated with respect to the oracle, so results agree to ~1e-12 relative.
+#pragma once
+#include "sf_energy.h"
+#include "sf_pf.hip.h"
+
+#define SF_PFF_NTABLES 13
+#define SF_PFF_SCRATCH_DOUBLES(W) (SF_PFF_NTABLES * (size_t)(W) * ((W) + 1))
+#define SF_PFF_MAXW 256
+
+struct SfPfTabs {
+  double *QB, *QBI, *QB1N, *QBB, *QM, *QM1, *OB, *OBI, *OB1N, *OBB, *OBW, *A0, *A1;
+};
+
+template <int NT>
+__global__ __launch_bounds__(NT) void sf_pf_fast_kernel(const uint8_t *__restrict__ seqs, int n, int row_stride, int W,
+                                                        const SfDevParams *__restrict__ D,
+                                                        const SfDevParamsPF *__restrict__ X,
+                                                        double *__restrict__ scratch, double *__restrict__ ens_dG,
+                                                        double *__restrict__ mean_bp_dist, char *__restrict__ centroid,
+                                                        double *__restrict__ centroid_dist) {
+  __shared__ uint8_t S[SF_PFF_MAXW + 2];
+  __shared__ double q5[SF_PFF_MAXW + 2];
+  __shared__ double q3[SF_PFF_MAXW + 3];
+  __shared__ double red[8];
+  const int tid = threadIdx.x;
+  const int W1 = W + 1;
+  const size_t TS = (size_t)W * W1;
+  SfPfTabs T;
+  {
+    double *b = scratch + (size_t)blockIdx.x * SF_PFF_SCRATCH_DOUBLES(W);
+    T.QB = b; T.QBI = b + TS; T.QB1N = b + 2 * TS; T.QBB = b + 3 * TS; T.QM = b + 4 * TS; T.QM1 = b + 5 * TS;
+    T.OB = b + 6 * TS; T.OBI = b + 7 * TS; T.OB1N = b + 8 * TS; T.OBB = b + 9 * TS; T.OBW = b + 10 * TS;
+    T.A0 = b + 11 * TS; T.A1 = b + 12 * TS;
+  }
+#define PT(tab, d, i) tab[(size_t)(d)*W1 + (i)]
+  const double *mlb = X->mlbase_pow;
+  const int OFF = (((W + 1) >> 1) - 32 + NT) & (NT - 1);
+  const int v = (tid + OFF) & (NT - 1);
+  const double xTAU = X->TermAU;
+
+  for (int k = blockIdx.x; k < n; k += gridDim.x) {
+    const uint8_t *src = seqs + (size_t)k * row_stride * W;
+    __syncthreads();
+    for (int x = tid; x < W; x += NT) S[x + 1] = sf_encode_nt(src[x]);
+    if (tid == 0) { S[0] = 0; S[W + 1] = 0; }
+    for (size_t x = tid; x < (size_t)4 * W1 && x < TS; x += NT) {
+      T.QB[x] = 0.0; T.QBI[x] = 0.0; T.QB1N[x] = 0.0; T.QBB[x] = 0.0; T.QM[x] = 0.0; T.QM1[x] = 0.0;
+    }
+    __syncthreads();
+
+    // ================= inside =================
+    double Ha[27], Hb[27];
+#pragma unroll
+    for (int u = 0; u < 27; u++) { Ha[u] = 0.0; Hb[u] = 0.0; }
+    auto inside_step = [&](const int d, double(&H)[27]) {
+      const int i = v - (d >> 1), j = i + d;
+      const bool valid = (i >= 1) && (j <= W);
+      if (valid) {
+        const int umax = sfd_min(SFD_MAXLOOP, d - 2 - (SFD_TURN + 1));
+        const int type = D->pair[S[i]][S[j]];
+        const int si1 = S[i + 1], sj1 = S[j - 1];
+        // generic interior sums of this cell from those of the enclosed cell
+#pragma unroll
+        for (int u = 30; u >= 6; --u)
+          if (u <= umax) H[u - 4] = H[u - 6] + (PT(T.QBI, d - 2 - u, i + 3) + PT(T.QBI, d - 2 - u, i + u - 1)) * X->ninio[u - 4];
+        if (umax >= 5) H[1] = (PT(T.QBI, d - 7, i + 3) + PT(T.QBI, d - 7, i + 4)) * X->ninio[1];
+        if (umax >= 4) H[0] = PT(T.QBI, d - 6, i + 3) * X->ninio[0];
+        double qbij = 0.0;
+        if (type) {
+          double z = sfx_hairpin(D, X, S, i, j, type);
+          if (umax >= 0) {
+            const double tau_out = type > 2 ? xTAU : 1.0;
+            z += PT(T.QB, d - 2, i + 1) * X->stack[type][sfd_rtype(D->pair[si1][sj1])];
+            if (umax >= 1) {
+              const int ta = sfd_rtype(D->pair[si1][S[j - 2]]), tb = sfd_rtype(D->pair[S[i + 2]][sj1]);
+              z += (PT(T.QB, d - 3, i + 1) * X->stack[type][ta] + PT(T.QB, d - 3, i + 2) * X->stack[type][tb]) * X->bulge[1];
+            }
+            if (umax >= 2) {
+              const int t2r = sfd_rtype(D->pair[S[i + 2]][S[j - 2]]);
+              z += PT(T.QB, d - 4, i + 2) * X->int11[type][t2r][si1][sj1];
+            }
+            if (umax >= 3) {
+              const int ta = sfd_rtype(D->pair[S[i + 2]][S[j - 3]]), tb = sfd_rtype(D->pair[S[i + 3]][S[j - 2]]);
+              z += PT(T.QB, d - 5, i + 2) * X->int21[type][ta][si1][S[j - 2]][sj1] +
+                   PT(T.QB, d - 5, i + 3) * X->int21[tb][type][sj1][si1][S[i + 2]];
+            }
+            if (umax >= 4) {
+              const int t2r = sfd_rtype(D->pair[S[i + 3]][S[j - 3]]);
+              z += PT(T.QB, d - 6, i + 3) * X->int22[type][t2r][si1][S[i + 2]][S[j - 2]][sj1];
+            }
+            if (umax >= 5) {
+              const int ta = sfd_rtype(D->pair[S[i + 3]][S[j - 4]]), tb = sfd_rtype(D->pair[S[i + 4]][S[j - 3]]);
+              const double m23 = X->internal_loop[5] * X->ninio[1] * X->mismatch23I[type][si1][sj1];
+              z += m23 * (PT(T.QB, d - 7, i + 3) * X->mismatch23I[ta][S[j - 3]][S[i + 2]] +
+                          PT(T.QB, d - 7, i + 4) * X->mismatch23I[tb][S[j - 2]][S[i + 3]]);
+            }
+            double gb = 0.0, g1 = 0.0, gg = 0.0;
+#pragma unroll
+            for (int u = 2; u <= 30; ++u)
+              if (u <= umax) {
+                gb += (PT(T.QBB, d - 2 - u, i + 1) + PT(T.QBB, d - 2 - u, i + 1 + u)) * X->bulge[u];
+                if (u >= 4)
+                  g1 += (PT(T.QB1N, d - 2 - u, i + 2) + PT(T.QB1N, d - 2 - u, i + u)) * X->internal_loop[u] * X->ninio[u - 2];
+                if (u >= 6) gg += H[u - 4] * X->internal_loop[u];
+              }
+            z += gb * tau_out + g1 * X->mismatch1nI[type][si1][sj1] + gg * X->mismatchI[type][si1][sj1];
+          }
+          double ml = 0.0;
+          for (int a = SFD_TURN + 2; a <= d - SFD_TURN - 2; a++) ml += PT(T.QM, a - 2, i + 1) * PT(T.QM1, d - 1 - a, i + a);
+          z += ml * X->MLclosing * sfx_mlstem(X, sfd_rtype(type), sj1, si1);
+          qbij = z;
+        }
+        {
+          const int tr = sfd_rtype(type);
+          const int sp1 = S[i - 1], sq1 = S[j + 1];
+          PT(T.QB, d, i) = qbij;
+          PT(T.QBI, d, i) = type ? qbij * X->mismatchI[tr][sq1][sp1] : 0.0;
+          PT(T.QB1N, d, i) = type ? qbij * X->mismatch1nI[tr][sq1][sp1] : 0.0;
+          PT(T.QBB, d, i) = (type && tr > 2) ? qbij * xTAU : qbij;
+          double m1 = PT(T.QM1, d - 1, i) * X->MLbase;
+          if (type) m1 += qbij * sfx_mlstem(X, type, i > 1 ? sp1 : -1, j < W ? sq1 : -1);
+          PT(T.QM1, d, i) = m1;
+          double m = m1;
+          for (int a = 1; a <= d - SFD_TURN - 1; a++) m += (mlb[a] + PT(T.QM, a - 1, i)) * PT(T.QM1, d - a, i + a);
+          PT(T.QM, d, i) = m;
+        }
+      }
+    };
+    for (int d = SFD_TURN + 1; d < W; d += 2) {  // even d -> Ha, odd d -> Hb
+      inside_step(d, Ha);
+      __syncthreads();
+      if (d + 1 < W) inside_step(d + 1, Hb);
+      __syncthreads();
+    }
+
+    // ================= exterior =================
+    if (tid == 0) { q5[0] = 1.0; q3[W + 1] = 1.0; }
+    __syncthreads();
+    for (int j = 1; j <= W; j++) {
+      double val = 0.0;
+      const int i = tid + 1;
+      if (i + SFD_TURN + 1 <= j) {
+        const int type = D->pair[S[i]][S[j]];
+        if (type) val = q5[i - 1] * PT(T.QB, j - i, i) * sfx_extloop(X, type, i > 1 ? S[i - 1] : -1, j < W ? S[j + 1] : -1);
+      }
+      val = sf_block_sum(val, red);
+      if (tid == 0) q5[j] = q5[j - 1] + val;
+      __syncthreads();
+    }
+    for (int i = W; i >= 1; i--) {
+      double val = 0.0;
+      const int j = tid + 1;
+      if (j <= W && i + SFD_TURN + 1 <= j) {
+        const int type = D->pair[S[i]][S[j]];
+        if (type) val = PT(T.QB, j - i, i) * sfx_extloop(X, type, i > 1 ? S[i - 1] : -1, j < W ? S[j + 1] : -1) * q3[j + 1];
+      }
+      val = sf_block_sum(val, red);
+      if (tid == 0) q3[i] = q3[i + 1] + val;
+      __syncthreads();
+    }
+    const double Z = q5[W];
+    if (centroid)
+      for (int x = tid; x <= W; x += NT) centroid[(size_t)k * W1 + x] = (x < W) ? '.' : 0;
+
+    // ================= outside (descending d) =================
+#pragma unroll
+    for (int u = 0; u < 27; u++) { Ha[u] = 0.0; Hb[u] = 0.0; }
+    double mbd = 0.0, cd = 0.0;
+    auto outside_step = [&](const int d, double(&G)[27]) {
+      const int i = v - (d >> 1), j = i + d;
+      const bool valid = (i >= 1) && (j <= W);
+      if (valid) {
+        const bool inner = (i > 1) && (j < W);  // (i,j) can be enclosed by another pair
+        // largest loop size whose enclosing diagonal d+2+u still exists
+        const int uomax = sfd_min(SFD_MAXLOOP, W - 1 - d - 2);
+        if (!inner) {
+#pragma unroll
+          for (int u = 0; u < 27; u++) G[u] = 0.0;
+        } else {
+#pragma unroll
+          for (int u = 30; u >= 6; --u)
+            if (u <= uomax) {
+              const int dd = d + 2 + u;
+              const double e1 = (i - 3 >= 1 && j + u - 1 <= W) ? PT(T.OBI, dd, i - 3) : 0.0;      // u1 = 2
+              const double e2 = (i - u + 1 >= 1 && j + 3 <= W) ? PT(T.OBI, dd, i - u + 1) : 0.0;  // u2 = 2
+              G[u - 4] = G[u - 6] + (e1 + e2) * X->ninio[u - 4];
+            } else {
+              G[u - 4] = 0.0;
+            }
+          if (uomax >= 5) {
+            const double e1 = (i - 3 >= 1 && j + 4 <= W) ? PT(T.OBI, d + 7, i - 3) : 0.0;
+            const double e2 = (i - 4 >= 1 && j + 3 <= W) ? PT(T.OBI, d + 7, i - 4) : 0.0;
+            G[1] = (e1 + e2) * X->ninio[1];
+          } else G[1] = 0.0;
+          G[0] = (uomax >= 4 && i - 3 >= 1 && j + 3 <= W) ? PT(T.OBI, d + 6, i - 3) * X->ninio[0] : 0.0;
+        }
+        // helper tables for multiloops closed by (k, j), k < i: indexed by the closer's span dd = j - k
+        double a0 = 0.0, a1 = 0.0;
+        if (i > 1) {
+          a0 = PT(T.A0, d + 1, i - 1) * X->MLbase + PT(T.OBW, d + 1, i - 1);
+          for (int dd = d + SFD_TURN + 3; dd <= W - 1; dd++) {
+            const int kk = j - dd;
+            if (kk >= 1) a1 += PT(T.OBW, dd, kk) * PT(T.QM, dd - d - 2, kk + 1);
+          }
+        }
+        PT(T.A0, d, i) = a0;
+        PT(T.A1, d, i) = a1;
+        const int type = D->pair[S[i]][S[j]];
+        const double qbij = PT(T.QB, d, i);
+        double o = 0.0;
+        if (type && qbij != 0.0) {
+          o = q5[i - 1] * q3[j + 1] * sfx_extloop(X, type, i > 1 ? S[i - 1] : -1, j < W ? S[j + 1] : -1);
+          if (inner) {
+            const int rt = sfd_rtype(type);
+            const int sp1 = S[i - 1], sq1 = S[j + 1];
+            // special loops; (kk,l) is the enclosing pair, its type tk, its inner neighbours S[kk+1], S[l-1]
+#define OBV(kk, l) (((kk) >= 1 && (l) <= W) ? PT(T.OB, (l) - (kk), (kk)) : 0.0)
+#define TK(kk, l) (((kk) >= 1 && (l) <= W) ? D->pair[S[kk]][S[l]] : 0)
+            {
+              const int tk = TK(i - 1, j + 1);
+              o += OBV(i - 1, j + 1) * X->stack[tk][rt];
+            }
+            {
+              const int ta = TK(i - 1, j + 2), tb = TK(i - 2, j + 1);
+              o += (OBV(i - 1, j + 2) * X->stack[ta][rt] + OBV(i - 2, j + 1) * X->stack[tb][rt]) * X->bulge[1];
+            }
+            {
+              const int tk = TK(i - 2, j + 2);
+              o += OBV(i - 2, j + 2) * X->int11[tk][rt][S[i - 1]][S[j + 1]];
+            }
+            {
+              const int ta = TK(i - 2, j + 3);  // u1 = 1, u2 = 2
+              o += OBV(i - 2, j + 3) * X->int21[ta][rt][S[i - 1]][sq1][S[j + 2]];
+              const int tb = TK(i - 3, j + 2);  // u1 = 2, u2 = 1
+              o += OBV(i - 3, j + 2) * X->int21[rt][tb][sq1][S[i - 2]][sp1];
+            }
+            {
+              const int tk = TK(i - 3, j + 3);
+              o += OBV(i - 3, j + 3) * X->int22[tk][rt][S[i - 2]][sp1][sq1][S[j + 2]];
+            }
+            {
+              const double m23 = X->internal_loop[5] * X->ninio[1] * X->mismatch23I[rt][sq1][sp1];
+              const int ta = TK(i - 3, j + 4), tb = TK(i - 4, j + 3);
+              o += m23 * (OBV(i - 3, j + 4) * X->mismatch23I[ta][S[i - 2]][S[j + 3]] +
+                          OBV(i - 4, j + 3) * X->mismatch23I[tb][S[i - 3]][S[j + 2]]);
+            }
+#undef OBV
+#undef TK
+            double gb = 0.0, g1 = 0.0, gg = 0.0;
+#pragma unroll
+            for (int u = 2; u <= 30; ++u)
+              if (u <= uomax) {
+                const int dd = d + 2 + u;
+                const double b1 = (j + 1 + u <= W) ? PT(T.OBB, dd, i - 1) : 0.0;          // u1 = 0
+                const double b2 = (i - 1 - u >= 1) ? PT(T.OBB, dd, i - 1 - u) : 0.0;      // u2 = 0
+                gb += (b1 + b2) * X->bulge[u];
+                if (u >= 4) {
+                  const double n1 = (i - 2 >= 1 && j + u <= W) ? PT(T.OB1N, dd, i - 2) : 0.0;  // u1 = 1
+                  const double n2 = (i - u >= 1 && j + 2 <= W) ? PT(T.OB1N, dd, i - u) : 0.0;  // u2 = 1
+                  g1 += (n1 + n2) * X->internal_loop[u] * X->ninio[u - 2];
+                }
+                if (u >= 6) gg += G[u - 4] * X->internal_loop[u];
+              }
+            o += gb * (rt > 2 ? xTAU : 1.0) + g1 * X->mismatch1nI[rt][sq1][sp1] + gg * X->mismatchI[rt][sq1][sp1];
+            // (i,j) as a stem of a multiloop closed by (k,l): indexed by the span dd = l - i
+            double mlsum = 0.0;
+            for (int dd = d + 1; dd <= W - 1; dd++) {
+              const int l = i + dd;
+              if (l <= W) {
+                const double qmr = (dd - d - 2 >= 0) ? PT(T.QM, dd - d - 2, j + 1) : 0.0;
+                mlsum += PT(T.A1, dd, i) * (mlb[dd - d - 1] + qmr) + PT(T.A0, dd, i) * qmr;
+              }
+            }
+            o += mlsum * sfx_mlstem(X, type, sp1, sq1);
+          }
+        }
+        {
+          const int si1 = S[i + 1], sj1 = S[j - 1];
+          PT(T.OB, d, i) = o;
+          PT(T.OBI, d, i) = type ? o * X->mismatchI[type][si1][sj1] : 0.0;
+          PT(T.OB1N, d, i) = type ? o * X->mismatch1nI[type][si1][sj1] : 0.0;
+          PT(T.OBB, d, i) = (type > 2) ? o * xTAU : o;
+          PT(T.OBW, d, i) = type ? o * X->MLclosing * sfx_mlstem(X, sfd_rtype(type), sj1, si1) : 0.0;
+          const double p = o * qbij / Z;
+          mbd += p * (1.0 - p);
+          if (p > 0.5) {
+            cd += 1.0 - p;
+            if (centroid) { centroid[(size_t)k * W1 + i - 1] = '('; centroid[(size_t)k * W1 + j - 1] = ')'; }
+          } else cd += p;
+        }
+      }
+    };
+    {
+      int d = W - 1;
+      if (d & 1) {
+        outside_step(d, Hb);
+        __syncthreads();
+        d--;
+      }
+      for (; d >= SFD_TURN + 1; d -= 2) {
+        outside_step(d, Ha);
+        __syncthreads();
+        if (d - 1 >= SFD_TURN + 1) outside_step(d - 1, Hb);
+        __syncthreads();
+      }
+    }
+    mbd = sf_block_sum(mbd, red);
+    __syncthreads();
+    cd = sf_block_sum(cd, red);
+    if (tid == 0) {
+      if (ens_dG) ens_dG[k] = -log(Z) * X->kT / 1000.0;
+      if (mean_bp_dist) mean_bp_dist[k] = 2.0 * mbd;
+      if (centroid_dist) centroid_dist[k] = cd;
+    }
+  }
+#undef PT
+}
+
+template <typename... A>
+static inline void sf_pf_fast_launch(int grid, int W, hipStream_t st, A... args) {
+  if (W <= 128) SF_LAUNCH(sf_pf_fast_kernel<128>, grid, 128, 0, st, args...);
+  else SF_LAUNCH(sf_pf_fast_kernel<256>, grid, 256, 0, st, args...);
+}

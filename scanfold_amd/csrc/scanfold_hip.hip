@@ -44,6 +44,7 @@ struct Ctx {
   int64_t prof_launches = 0, prof_folds = 0;
   int force_full = 0;
   int fast_ok = 0;
+  int pf_blocks_per_cu = 4;  // 256 VGPRs per thread: 2 waves per SIMD
 } g;
 
 #define HIPCHK(call)                                                              \
@@ -177,6 +178,8 @@ int launch_pf(const uint8_t *d_seqs, int n, int row_stride, int W, double *d_dG,
   if (n <= 0) return SF_OK;
   int grid = n < max_resident_blocks() ? n : max_resident_blocks();
   if (W >= 16 && W <= SF_PFF_MAXW && !g.force_full) {
+    const int pf_blocks = g.n_cu * g.pf_blocks_per_cu;
+    grid = n < pf_blocks ? n : pf_blocks;
     int rc = ensure(g.pf_scratch, (size_t)grid * SF_PFF_SCRATCH_DOUBLES(W) * sizeof(double));
     if (rc) return rc;
     sf_pf_fast_launch(grid, W, st, d_seqs, n, row_stride, W, (const SfDevParams *)g.dP, (const SfDevParamsPF *)g.dX,

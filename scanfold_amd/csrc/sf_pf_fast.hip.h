@@ -14,6 +14,7 @@
 #pragma once
 #include "sf_energy.h"
 #include "sf_pf.hip.h"
+#include <type_traits>
 
 #define SF_PFF_NTABLES 13
 #define SF_PFF_SCRATCH_DOUBLES(W) (SF_PFF_NTABLES * (size_t)(W) * ((W) + 1))
@@ -64,43 +65,46 @@ __global__ __launch_bounds__(NT) void sf_pf_fast_kernel(const uint8_t *__restric
     double Ha[27], Hb[27];
 #pragma unroll
     for (int u = 0; u < 27; u++) { Ha[u] = 0.0; Hb[u] = 0.0; }
-    auto inside_step = [&](const int d, double(&H)[27]) {
+    // GT = std::true_type: loop sizes are tested against the limit d-6.  (A false_type instantiation makes the
+    // candidate code straight-line; in FP64 that needs >256 VGPRs and spills, so it is not used.)
+    auto inside_step = [&](const int d, double(&H)[27], auto GT) {
+      constexpr bool G = decltype(GT)::value;
       const int i = v - (d >> 1), j = i + d;
       const bool valid = (i >= 1) && (j <= W);
       if (valid) {
-        const int umax = sfd_min(SFD_MAXLOOP, d - 2 - (SFD_TURN + 1));
+        const int umax = G ? sfd_min(SFD_MAXLOOP, d - 2 - (SFD_TURN + 1)) : SFD_MAXLOOP;
         const int type = D->pair[S[i]][S[j]];
         const int si1 = S[i + 1], sj1 = S[j - 1];
         // generic interior sums of this cell from those of the enclosed cell
 #pragma unroll
         for (int u = 30; u >= 6; --u)
-          if (u <= umax) H[u - 4] = H[u - 6] + (PT(T.QBI, d - 2 - u, i + 3) + PT(T.QBI, d - 2 - u, i + u - 1)) * X->ninio[u - 4];
-        if (umax >= 5) H[1] = (PT(T.QBI, d - 7, i + 3) + PT(T.QBI, d - 7, i + 4)) * X->ninio[1];
-        if (umax >= 4) H[0] = PT(T.QBI, d - 6, i + 3) * X->ninio[0];
+          if (!G || u <= umax) H[u - 4] = H[u - 6] + (PT(T.QBI, d - 2 - u, i + 3) + PT(T.QBI, d - 2 - u, i + u - 1)) * X->ninio[u - 4];
+        if (!G || umax >= 5) H[1] = (PT(T.QBI, d - 7, i + 3) + PT(T.QBI, d - 7, i + 4)) * X->ninio[1];
+        if (!G || umax >= 4) H[0] = PT(T.QBI, d - 6, i + 3) * X->ninio[0];
         double qbij = 0.0;
         if (type) {
           double z = sfx_hairpin(D, X, S, i, j, type);
-          if (umax >= 0) {
+          if (!G || umax >= 0) {
             const double tau_out = type > 2 ? xTAU : 1.0;
             z += PT(T.QB, d - 2, i + 1) * X->stack[type][sfd_rtype(D->pair[si1][sj1])];
-            if (umax >= 1) {
+            if (!G || umax >= 1) {
               const int ta = sfd_rtype(D->pair[si1][S[j - 2]]), tb = sfd_rtype(D->pair[S[i + 2]][sj1]);
               z += (PT(T.QB, d - 3, i + 1) * X->stack[type][ta] + PT(T.QB, d - 3, i + 2) * X->stack[type][tb]) * X->bulge[1];
             }
-            if (umax >= 2) {
+            if (!G || umax >= 2) {
               const int t2r = sfd_rtype(D->pair[S[i + 2]][S[j - 2]]);
               z += PT(T.QB, d - 4, i + 2) * X->int11[type][t2r][si1][sj1];
             }
-            if (umax >= 3) {
+            if (!G || umax >= 3) {
               const int ta = sfd_rtype(D->pair[S[i + 2]][S[j - 3]]), tb = sfd_rtype(D->pair[S[i + 3]][S[j - 2]]);
               z += PT(T.QB, d - 5, i + 2) * X->int21[type][ta][si1][S[j - 2]][sj1] +
                    PT(T.QB, d - 5, i + 3) * X->int21[tb][type][sj1][si1][S[i + 2]];
             }
-            if (umax >= 4) {
+            if (!G || umax >= 4) {
               const int t2r = sfd_rtype(D->pair[S[i + 3]][S[j - 3]]);
               z += PT(T.QB, d - 6, i + 3) * X->int22[type][t2r][si1][S[i + 2]][S[j - 2]][sj1];
             }
-            if (umax >= 5) {
+            if (!G || umax >= 5) {
               const int ta = sfd_rtype(D->pair[S[i + 3]][S[j - 4]]), tb = sfd_rtype(D->pair[S[i + 4]][S[j - 3]]);
               const double m23 = X->internal_loop[5] * X->ninio[1] * X->mismatch23I[type][si1][sj1];
               z += m23 * (PT(T.QB, d - 7, i + 3) * X->mismatch23I[ta][S[j - 3]][S[i + 2]] +
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(NT) void sf_pf_fast_kernel(const uint8_t *__restric
             double gb = 0.0, g1 = 0.0, gg = 0.0;
 #pragma unroll
             for (int u = 2; u <= 30; ++u)
-              if (u <= umax) {
+              if (!G || u <= umax) {
                 gb += (PT(T.QBB, d - 2 - u, i + 1) + PT(T.QBB, d - 2 - u, i + 1 + u)) * X->bulge[u];
                 if (u >= 4)
                   g1 += (PT(T.QB1N, d - 2 - u, i + 2) + PT(T.QB1N, d - 2 - u, i + u)) * X->internal_loop[u] * X->ninio[u - 2];
@@ -118,6 +122,7 @@ __global__ __launch_bounds__(NT) void sf_pf_fast_kernel(const uint8_t *__restric
             z += gb * tau_out + g1 * X->mismatch1nI[type][si1][sj1] + gg * X->mismatchI[type][si1][sj1];
           }
           double ml = 0.0;
+#pragma unroll 4
           for (int a = SFD_TURN + 2; a <= d - SFD_TURN - 2; a++) ml += PT(T.QM, a - 2, i + 1) * PT(T.QM1, d - 1 - a, i + a);
           z += ml * X->MLclosing * sfx_mlstem(X, sfd_rtype(type), sj1, si1);
           qbij = z;
@@ -133,15 +138,18 @@ __global__ __launch_bounds__(NT) void sf_pf_fast_kernel(const uint8_t *__restric
           if (type) m1 += qbij * sfx_mlstem(X, type, i > 1 ? sp1 : -1, j < W ? sq1 : -1);
           PT(T.QM1, d, i) = m1;
           double m = m1;
+#pragma unroll 4
           for (int a = 1; a <= d - SFD_TURN - 1; a++) m += (mlb[a] + PT(T.QM, a - 1, i)) * PT(T.QM1, d - a, i + a);
           PT(T.QM, d, i) = m;
         }
       }
     };
     for (int d = SFD_TURN + 1; d < W; d += 2) {  // even d -> Ha, odd d -> Hb
-      inside_step(d, Ha);
+      inside_step(d, Ha, std::true_type{});
       __syncthreads();
-      if (d + 1 < W) inside_step(d + 1, Hb);
+      if (d + 1 < W) {
+        inside_step(d + 1, Hb, std::true_type{});
+      }
       __syncthreads();
     }
 
@@ -178,20 +186,21 @@ __global__ __launch_bounds__(NT) void sf_pf_fast_kernel(const uint8_t *__restric
 #pragma unroll
     for (int u = 0; u < 27; u++) { Ha[u] = 0.0; Hb[u] = 0.0; }
     double mbd = 0.0, cd = 0.0;
-    auto outside_step = [&](const int d, double(&G)[27]) {
+    auto outside_step = [&](const int d, double(&G)[27], auto GT) {
+      constexpr bool GU = decltype(GT)::value;  // true: some enclosing diagonals d+2+u fall outside the table
       const int i = v - (d >> 1), j = i + d;
       const bool valid = (i >= 1) && (j <= W);
       if (valid) {
         const bool inner = (i > 1) && (j < W);  // (i,j) can be enclosed by another pair
         // largest loop size whose enclosing diagonal d+2+u still exists
-        const int uomax = sfd_min(SFD_MAXLOOP, W - 1 - d - 2);
+        const int uomax = GU ? sfd_min(SFD_MAXLOOP, W - 1 - d - 2) : SFD_MAXLOOP;
         if (!inner) {
 #pragma unroll
           for (int u = 0; u < 27; u++) G[u] = 0.0;
         } else {
 #pragma unroll
           for (int u = 30; u >= 6; --u)
-            if (u <= uomax) {
+            if (!GU || u <= uomax) {
               const int dd = d + 2 + u;
               const double e1 = (i - 3 >= 1 && j + u - 1 <= W) ? PT(T.OBI, dd, i - 3) : 0.0;      // u1 = 2
               const double e2 = (i - u + 1 >= 1 && j + 3 <= W) ? PT(T.OBI, dd, i - u + 1) : 0.0;  // u2 = 2
@@ -199,17 +208,18 @@ __global__ __launch_bounds__(NT) void sf_pf_fast_kernel(const uint8_t *__restric
             } else {
               G[u - 4] = 0.0;
             }
-          if (uomax >= 5) {
+          if (!GU || uomax >= 5) {
             const double e1 = (i - 3 >= 1 && j + 4 <= W) ? PT(T.OBI, d + 7, i - 3) : 0.0;
             const double e2 = (i - 4 >= 1 && j + 3 <= W) ? PT(T.OBI, d + 7, i - 4) : 0.0;
             G[1] = (e1 + e2) * X->ninio[1];
           } else G[1] = 0.0;
-          G[0] = (uomax >= 4 && i - 3 >= 1 && j + 3 <= W) ? PT(T.OBI, d + 6, i - 3) * X->ninio[0] : 0.0;
+          G[0] = ((!GU || uomax >= 4) && i - 3 >= 1 && j + 3 <= W) ? PT(T.OBI, d + 6, i - 3) * X->ninio[0] : 0.0;
         }
         // helper tables for multiloops closed by (k, j), k < i: indexed by the closer's span dd = j - k
         double a0 = 0.0, a1 = 0.0;
         if (i > 1) {
           a0 = PT(T.A0, d + 1, i - 1) * X->MLbase + PT(T.OBW, d + 1, i - 1);
+#pragma unroll 4
           for (int dd = d + SFD_TURN + 3; dd <= W - 1; dd++) {
             const int kk = j - dd;
             if (kk >= 1) a1 += PT(T.OBW, dd, kk) * PT(T.QM, dd - d - 2, kk + 1);
@@ -261,7 +271,7 @@ __global__ __launch_bounds__(NT) void sf_pf_fast_kernel(const uint8_t *__restric
             double gb = 0.0, g1 = 0.0, gg = 0.0;
 #pragma unroll
             for (int u = 2; u <= 30; ++u)
-              if (u <= uomax) {
+              if (!GU || u <= uomax) {
                 const int dd = d + 2 + u;
                 const double b1 = (j + 1 + u <= W) ? PT(T.OBB, dd, i - 1) : 0.0;          // u1 = 0
                 const double b2 = (i - 1 - u >= 1) ? PT(T.OBB, dd, i - 1 - u) : 0.0;      // u2 = 0
@@ -276,6 +286,7 @@ __global__ __launch_bounds__(NT) void sf_pf_fast_kernel(const uint8_t *__restric
             o += gb * (rt > 2 ? xTAU : 1.0) + g1 * X->mismatch1nI[rt][sq1][sp1] + gg * X->mismatchI[rt][sq1][sp1];
             // (i,j) as a stem of a multiloop closed by (k,l): indexed by the span dd = l - i
             double mlsum = 0.0;
+#pragma unroll 4
             for (int dd = d + 1; dd <= W - 1; dd++) {
               const int l = i + dd;
               if (l <= W) {
@@ -305,14 +316,16 @@ __global__ __launch_bounds__(NT) void sf_pf_fast_kernel(const uint8_t *__restric
     {
       int d = W - 1;
       if (d & 1) {
-        outside_step(d, Hb);
+        outside_step(d, Hb, std::true_type{});
         __syncthreads();
         d--;
       }
       for (; d >= SFD_TURN + 1; d -= 2) {
-        outside_step(d, Ha);
+        outside_step(d, Ha, std::true_type{});
         __syncthreads();
-        if (d - 1 >= SFD_TURN + 1) outside_step(d - 1, Hb);
+        if (d - 1 >= SFD_TURN + 1) {
+          outside_step(d - 1, Hb, std::true_type{});
+        }
         __syncthreads();
       }
     }

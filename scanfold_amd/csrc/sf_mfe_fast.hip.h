@@ -37,13 +37,16 @@
 #pragma once
 #include "sf_energy.h"
 
-#define SF_FAST_NR 33
+#define SF_FAST_NR 34
 #define SF_INF16 30000
 #define SF_FAST_THRESH 10000
 #define SF_FAST_OVF (-12000)
 #define SF_FAST_MAXPARAM 2500
 #define SF_FAST_MAXW 256
 #define SF_FAST_BIG 60000
+#ifndef SF_FAST_WAVES_PER_SIMD
+#define SF_FAST_WAVES_PER_SIMD 4  // 4 workgroups of 4 waves per CU (W <= 128): at most 128 VGPRs
+#endif
 
 struct SfFastParams {
   int32_t NIN[32];   // [a]  min(max_ninio, a * ninio)
@@ -119,11 +122,12 @@ static inline __host__ __device__ SfFastLayout sf_fast_layout(int W) {
   tri = (tri + 1) & ~1;
   L.tri = tri;
   int o = tri * 2;
-  const int roll = ((SF_FAST_NR * W + 1) & ~1) * 2;
+  const int RW = W - 4;  // a diagonal d >= 4 has at most W-4 cells
+  const int roll = ((SF_FAST_NR * RW + 1) & ~1) * 2;
   L.off_ci = o; o += roll;   // the exterior pass reuses this area for f5[] and the mismatchExt table
   L.off_c1n = o; o += roll;
   L.off_cb = o; o += roll;
-  L.off_dml = o; o += ((3 * W + 1) & ~1) * 2;
+  L.off_dml = o; o += ((4 * RW + 1) & ~1) * 2;
   L.off_tab = o; o += SF_FAST_TAB_BYTES;
   L.off_red = o; o += 8 * 4;
   L.off_flag = o; o += 4;
@@ -133,7 +137,7 @@ static inline __host__ __device__ SfFastLayout sf_fast_layout(int W) {
 }
 
 static inline bool sf_fast_w_supported(int W) { return W >= 16 && W <= SF_FAST_MAXW; }
-static inline int sf_fast_threads(int W) { return W <= 128 ? 128 : 256; }
+static inline int sf_fast_threads(int W) { return W <= 128 ? 256 : 512; }  // two diagonal groups of 128 / 256
 
 struct SfFastCtx {
   int16_t *fML, *CI, *C1N, *CB, *DMLr;
@@ -163,8 +167,9 @@ struct SfFastCtx {
 // !G: all sizes 0..30 exist, the candidate code is one straight-line block the scheduler can pipeline.
 template <bool G>
 __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, const int i, const bool valid,
-                                             const int slot2, const int slotd, int (&H)[27], int &ovf) {
-  const int W = X.W;
+                                             const int slot2, const int slotd, int (&H)[27], int &ovf,
+                                             const bool final_fml, int &fpart) {
+  const int W = X.W, RW = W - 4;
   if (!valid) return;
   const int j = i + d, i0 = i - 1;
   const uint8_t *S = X.S;
@@ -174,7 +179,7 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
 // fML triangle without diagonals 0..3: base(d) = sum_{k=4}^{d-1} (W-k)
 #define FBASE(dd) (((dd)-4) * W - ((dd) * ((dd)-1) / 2 - 6))
 // row of diagonal d-2-u in the rolling tables
-#define ROW(u) ((slot2 - (u) < 0 ? slot2 - (u) + SF_FAST_NR : slot2 - (u)) * W)
+#define ROW(u) ((slot2 - (u) < 0 ? slot2 - (u) + SF_FAST_NR : slot2 - (u)) * RW)
 
   // ---- pass 1 (every cell): per-size minima of the generic interior candidates ----
 #ifndef SF_ABL_PASS1
@@ -261,7 +266,7 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
     // multiloop closed by (i,j)
     {
       const int tr = sfd_rtype(type);
-      const int dml = X.DMLr[((d - 2) % 3) * W + i0 + 1];
+      const int dml = X.DMLr[((d - 2) & 3) * RW + i0 + 1];
       e = sfd_min(e, dml + X.tM[SF_TIDX(tr, sj1, si1)] + (tr > 2 ? TAU : 0) + X.MLintern + X.MLclosing);
     }
     c = e;
@@ -269,7 +274,7 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
   }
 
   // ---- publish the cell ----
-  const int rbd = slotd * W + i0;
+  const int rbd = slotd * RW + i0;
   int f = SF_FAST_BIG;
   if (type) {
     const int tr = sfd_rtype(type);
@@ -288,8 +293,8 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
     X.CI[rbd] = SF_INF16; X.C1N[rbd] = SF_INF16; X.CB[rbd] = SF_INF16;
   }
   X.cg[(j - 1) * W + i0] = (int16_t)c;  // row j, column i: the exterior pass reads rows coalesced
-  // fML[i,j]
-  if (d > SFD_TURN + 1) {
+  // fML[i,j]: the two neighbours on diagonal d-1 are final only for the even-diagonal group (see the kernel)
+  if (final_fml && d > SFD_TURN + 1) {
     const int fb = FBASE(d - 1);
     f = sfd_min(f, sfd_min(X.fML[fb + i0 + 1], X.fML[fb + i0]) + X.MLbase);
   }
@@ -329,9 +334,12 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
   }
 #endif
   f = sfd_min(f, dec);
-  if (f < SF_FAST_OVF) ovf = 1;
-  X.DMLr[(d % 3) * W + i0] = (int16_t)(dec > SF_FAST_THRESH ? SF_INF16 : dec);
-  X.fML[FBASE(d) + i0] = (int16_t)(f > SF_FAST_THRESH ? SF_INF16 : f);
+  X.DMLr[(d & 3) * RW + i0] = (int16_t)(dec > SF_FAST_THRESH ? SF_INF16 : dec);
+  fpart = f;
+  if (final_fml) {
+    if (f < SF_FAST_OVF) ovf = 1;
+    X.fML[FBASE(d) + i0] = (int16_t)(f > SF_FAST_THRESH ? SF_INF16 : f);
+  }
 #undef ROW
 }
 
@@ -471,16 +479,22 @@ __device__ inline int sf_fast_traceback(const SfFastCtx &X, const int32_t *f5s, 
   return bad;
 }
 
-template <int NT>
-__global__ __launch_bounds__(NT) void sf_mfe_fast_kernel(const uint8_t *__restrict__ seqs, int n, int W,
-                                                         const SfDevParams *__restrict__ D,
-                                                         const SfFastParams *__restrict__ F,
-                                                         int16_t *__restrict__ cg_all, int32_t *__restrict__ out,
-                                                         int *__restrict__ ovf_cnt, int *__restrict__ ovf_list,
-                                                         int trace_stride, char *__restrict__ db_out,
-                                                         int *__restrict__ status) {
+// NG = threads per diagonal group.  The workgroup has two groups: group 0 handles the even diagonals, group 1
+// the odd ones.  c[.,.] of diagonal d+1 does not depend on diagonal d (an enclosed pair spans at most d-1, the
+// multiloop split of d+1 reads fML spans <= d-3), only fML[d+1] needs its two neighbours on d — so the pair
+// (d, d+1) is computed concurrently by the two groups, then group 1 adds the neighbour term after one barrier.
+template <int NG>
+__global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_kernel(const uint8_t *__restrict__ seqs, int n, int W,
+                                                             const SfDevParams *__restrict__ D,
+                                                             const SfFastParams *__restrict__ F,
+                                                             int16_t *__restrict__ cg_all, int32_t *__restrict__ out,
+                                                             int *__restrict__ ovf_cnt, int *__restrict__ ovf_list,
+                                                             int trace_stride, char *__restrict__ db_out,
+                                                             int *__restrict__ status) {
+  constexpr int NT = 2 * NG;
   SF_DYN_SMEM(smem);
   const SfFastLayout Lo = sf_fast_layout(W);
+  const int RW = W - 4;
   SfFastCtx X;
   X.fML = (int16_t *)smem;
   X.CI = (int16_t *)(smem + Lo.off_ci);
@@ -503,7 +517,7 @@ __global__ __launch_bounds__(NT) void sf_mfe_fast_kernel(const uint8_t *__restri
   int16_t *tExt = (int16_t *)(smem + Lo.off_ci + (((W + 1) * 4 + 3) & ~3));
 
   const int tid = threadIdx.x;
-  X.cg = cg_all + (size_t)blockIdx.x * W * W;  // c[d][i0] for the exterior pass
+  X.cg = cg_all + (size_t)blockIdx.x * W * W;  // c by (row j, column i) for the exterior pass / traceback
   // parameter tables -> LDS, once per workgroup
   for (int x = tid; x < 200; x += NT) {
     tab[x] = F->mmI[x]; tab[200 + x] = F->mm1n[x]; tab[400 + x] = F->mm23[x]; tab[600 + x] = F->mmM[x];
@@ -516,55 +530,49 @@ __global__ __launch_bounds__(NT) void sf_mfe_fast_kernel(const uint8_t *__restri
     const int lk = tid & 31;
     X.vNIN = F->NIN[lk]; X.vIL = F->IL[lk]; X.vL1N = F->L1N[lk]; X.vBUL = F->BUL[lk];
   }
-  // centre-based thread mapping: v = (tid + OFF) mod NT, cell i = v - d/2
-  const int OFF = (NT > 64) ? (((W + 1) >> 1) - 32 + NT) & (NT - 1) : 0;
-  const int v = (tid + OFF) & (NT - 1);
+  // group and centre-based mapping inside the group: v = (tg + OFF) mod NG, cell i = v - d/2
+  const int grp = tid / NG, tg = tid - grp * NG;
+  const int OFF = (NG > 64) ? (((W + 1) >> 1) - 32 + NG) & (NG - 1) : 0;
+  const int v = (tg + OFF) & (NG - 1);
 
   for (int seq = blockIdx.x; seq < n; seq += gridDim.x) {
     const uint8_t *src = seqs + (size_t)seq * W;
     __syncthreads();
     for (int x = tid; x < W; x += NT) S[x + 1] = sf_encode_nt(src[x]);
     if (tid == 0) { S[0] = 0; S[W + 1] = 0; flag[0] = 0; }
-    for (int x = tid; x < 3 * W; x += NT) X.DMLr[x] = SF_INF16;  // diagonals 2,3 have no multiloop split
+    for (int x = tid; x < 4 * RW; x += NT) X.DMLr[x] = SF_INF16;  // diagonals 2,3 have no multiloop split
     __syncthreads();
     int ovf = 0;
-    int Ha[27], Hb[27];
+    int H[27];
 #pragma unroll
-    for (int k = 0; k < 27; k++) { Ha[k] = SF_FAST_BIG; Hb[k] = SF_FAST_BIG; }
+    for (int k = 0; k < 27; k++) H[k] = SF_FAST_BIG;
 
-    int slot2 = 2, slotd = 4;  // (d-2) mod NR and d mod NR for d = 4
-    for (int d = SFD_TURN + 1; d < W; d += 2) {
-      {
-        const int i = v - (d >> 1);
-        const bool valid = (i >= 1) && (i + d <= W);
+    // this thread's diagonal in the step that starts at the even diagonal d0 is d0 + grp
+    int slot2 = (SFD_TURN + 1 + grp - 2) % SF_FAST_NR, slotd = (SFD_TURN + 1 + grp) % SF_FAST_NR;
+    for (int d0 = SFD_TURN + 1; d0 < W; d0 += 2) {
+      const int d = d0 + grp;
+      const int i = v - (d >> 1);
+      const bool valid = (d < W) && (i >= 1) && (i + d <= W);
+      int fpart = SF_FAST_BIG;
 #ifdef SF_ABL_CELL
-        if (0) {
+      if (0) {
 #else
-        if (__ballot(valid)) {
+      if (__ballot(valid)) {
 #endif
-          if (d < SFD_MAXLOOP + 6) sf_fast_cell<true>(X, d, i, valid, slot2, slotd, Ha, ovf);
-          else sf_fast_cell<false>(X, d, i, valid, slot2, slotd, Ha, ovf);
-        }
+        if (d0 < SFD_MAXLOOP + 6) sf_fast_cell<true>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fpart);
+        else sf_fast_cell<false>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fpart);
       }
       __syncthreads();
-      slot2 = slot2 + 1 == SF_FAST_NR ? 0 : slot2 + 1;
-      slotd = slotd + 1 == SF_FAST_NR ? 0 : slotd + 1;
-      if (d + 1 < W) {
-        const int d1 = d + 1;
-        const int i = v - (d1 >> 1);
-        const bool valid = (i >= 1) && (i + d1 <= W);
-#ifdef SF_ABL_CELL
-        if (0) {
-#else
-        if (__ballot(valid)) {
-#endif
-          if (d1 < SFD_MAXLOOP + 6) sf_fast_cell<true>(X, d1, i, valid, slot2, slotd, Hb, ovf);
-          else sf_fast_cell<false>(X, d1, i, valid, slot2, slotd, Hb, ovf);
-        }
+      if (grp == 1 && valid) {  // fML[i,j] on the odd diagonal: add the neighbours on diagonal d-1, now final
+        const int i0 = i - 1;
+        const int fb = FBASE(d - 1);
+        const int f = sfd_min(fpart, sfd_min(X.fML[fb + i0 + 1], X.fML[fb + i0]) + X.MLbase);
+        if (f < SF_FAST_OVF) ovf = 1;
+        X.fML[FBASE(d) + i0] = (int16_t)(f > SF_FAST_THRESH ? SF_INF16 : f);
       }
       __syncthreads();
-      slot2 = slot2 + 1 == SF_FAST_NR ? 0 : slot2 + 1;
-      slotd = slotd + 1 == SF_FAST_NR ? 0 : slotd + 1;
+      slot2 += 2; if (slot2 >= SF_FAST_NR) slot2 -= SF_FAST_NR;
+      slotd += 2; if (slotd >= SF_FAST_NR) slotd -= SF_FAST_NR;
     }
 
     // ---- exterior loop f5[j] = min(f5[j-1], min_i f5[i-1] + c[i,j] + ExtLoop(i,j)) : wave 0 only ----
@@ -574,7 +582,7 @@ __global__ __launch_bounds__(NT) void sf_mfe_fast_kernel(const uint8_t *__restri
     for (int x = tid; x < 200; x += NT) tExt[x] = F->mmExt[x];
     __syncthreads();
     if (tid < 64) {
-      constexpr int NQ = NT / 64;
+      constexpr int NQ = NG / 64;
       const int lane = tid;
       int f5r[NQ], cn[NQ], si[NQ], sim1[NQ];
 #pragma unroll
@@ -670,6 +678,6 @@ static inline void sf_fast_geometry(int W, int n_cu, int n, int *grid, int *thre
 
 template <typename... A>
 static inline void sf_fast_launch(int grid, int threads, size_t lds, hipStream_t st, A... args) {
-  if (threads == 128) SF_LAUNCH(sf_mfe_fast_kernel<128>, grid, 128, lds, st, args...);
-  else SF_LAUNCH(sf_mfe_fast_kernel<256>, grid, 256, lds, st, args...);
+  if (threads == 256) SF_LAUNCH(sf_mfe_fast_kernel<128>, grid, 256, lds, st, args...);
+  else SF_LAUNCH(sf_mfe_fast_kernel<256>, grid, 512, lds, st, args...);
 }

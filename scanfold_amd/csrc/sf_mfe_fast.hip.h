@@ -343,6 +343,23 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
 #undef ROW
 }
 
+// minimum over the 64 lanes of a wave, returned in every lane.  DPP row operations + one readlane: no LDS
+// round trips (the generic __shfl_xor butterfly lowers to ds_bpermute, ~6 dependent LDS-crossbar trips).
+__device__ __forceinline__ int sf_wave_min(int v) {
+#ifdef SF_EMUL
+  for (int m = 32; m >= 1; m >>= 1) v = sfd_min(v, __shfl_xor(v, m));
+  return v;
+#else
+  v = sfd_min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+  v = sfd_min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+  v = sfd_min(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false));  // row_half_mirror
+  v = sfd_min(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false));  // row_mirror
+  v = sfd_min(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xA, 0xF, false));  // row_bcast:15 -> rows 1,3
+  v = sfd_min(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xC, 0xF, false));  // row_bcast:31 -> rows 2,3
+  return __builtin_amdgcn_readlane(v, 63);
+#endif
+}
+
 // Wave-cooperative traceback over the tables the fill left behind (fML triangle in LDS, c in device memory,
 // f5 in LDS).  Same order of alternatives as sf_mfe_full_kernel / the oracle; candidate
 // tests are spread over the 64 lanes and the first hit in that order is taken with ballot + ffs.
@@ -584,49 +601,60 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
     if (tid < 64) {
       constexpr int NQ = NG / 64;
       const int lane = tid;
-      int f5r[NQ], cn[NQ], si[NQ], sim1[NQ];
+      int f5r[NQ], si[NQ], sim1[NQ];
 #pragma unroll
       for (int q = 0; q < NQ; q++) {
         const int i = lane + 64 * q + 1;
         f5r[q] = 0;
         si[q] = i <= W ? S[i] : 0;
         sim1[q] = i <= W ? S[i - 1] : 0;
-        cn[q] = i <= W ? X.cg[i - 1] : SF_INF16;
       }
       int f5prev = 0;
       if (lane == 0) f5s[0] = 0;
+      constexpr int RB = 8;  // rows of c fetched per batch: one memory round trip per RB values of j
 #ifdef SF_ABL_F5
-      for (int j = W; j <= W; j++) {
+      for (int j0 = W; j0 <= W; j0 += RB) {
 #else
-      for (int j = 1; j <= W; j++) {
+      for (int j0 = 1; j0 <= W; j0 += RB) {
 #endif
-        int cc[NQ];
-        const int sj = S[j], sj1 = S[j + 1];
-        int val = SF_FAST_BIG * 2;
+        int cbuf[RB][NQ];
 #pragma unroll
-        for (int q = 0; q < NQ; q++) {
-          const int i = lane + 64 * q + 1;
-          cc[q] = cn[q];
-          if (j < W && i <= W) cn[q] = X.cg[j * W + i - 1];
-          if (i + SFD_TURN + 1 <= j) {
-            const int type = tPair[si[q] * 8 + sj];
-            if (type) {
-              int ext;
-              if (i > 1 && j < W) ext = tExt[SF_TIDX(type, sim1[q], sj1)];
-              else if (i > 1) ext = X.tD5[type * 5 + sim1[q]];
-              else if (j < W) ext = X.tD3[type * 5 + sj1];
-              else ext = 0;
-              val = sfd_min(val, f5r[q] + cc[q] + ext + (type > 2 ? X.TAU : 0));
+        for (int k = 0; k < RB; k++)
+#pragma unroll
+          for (int q = 0; q < NQ; q++) {
+            const int i = lane + 64 * q + 1, j = j0 + k;
+            cbuf[k][q] = (j <= W && i <= W) ? (int)X.cg[(j - 1) * W + i - 1] : SF_INF16;
+          }
+#pragma unroll
+        for (int k = 0; k < RB; k++) {
+          const int j = j0 + k;
+          if (j <= W) {
+            const int sj = S[j], sj1 = S[j + 1];
+            int val = SF_FAST_BIG * 2;
+#pragma unroll
+            for (int q = 0; q < NQ; q++) {
+              const int i = lane + 64 * q + 1;
+              if (i + SFD_TURN + 1 <= j) {
+                const int type = tPair[si[q] * 8 + sj];
+                if (type) {
+                  int ext;
+                  if (i > 1 && j < W) ext = tExt[SF_TIDX(type, sim1[q], sj1)];
+                  else if (i > 1) ext = X.tD5[type * 5 + sim1[q]];
+                  else if (j < W) ext = X.tD3[type * 5 + sj1];
+                  else ext = 0;
+                  val = sfd_min(val, f5r[q] + cbuf[k][q] + ext + (type > 2 ? X.TAU : 0));
+                }
+              }
             }
+            val = sf_wave_min(val);
+            const int f5j = sfd_min(f5prev, val);
+            f5prev = f5j;
+            if (lane == 0) f5s[j] = f5j;
+#pragma unroll
+            for (int q = 0; q < NQ; q++)
+              if (lane + 64 * q == j) f5r[q] = f5j;
           }
         }
-        for (int m = 32; m >= 1; m >>= 1) val = sfd_min(val, __shfl_xor(val, m));
-        const int f5j = sfd_min(f5prev, val);
-        f5prev = f5j;
-        if (lane == 0) f5s[j] = f5j;
-#pragma unroll
-        for (int q = 0; q < NQ; q++)
-          if (lane + 64 * q == j) f5r[q] = f5j;
       }
       SF_WAVE_SYNC();  // f5s[] was written by lane 0, the traceback reads it from every lane
       const int over = flag[0] || f5prev < SF_FAST_OVF;

@@ -8,6 +8,8 @@
 #define SF_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
 #define SF_LAUNCH(kern, grid, block, shmem, stream, ...) \
   hipLaunchKernelGGL(kern, dim3(grid), dim3(block), shmem, stream, __VA_ARGS__)
+// a value that is the same in every lane of the wave: tell the compiler (keeps derived index math scalar)
+#define SF_WAVE_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 // lanes of one wave exchanging data through LDS: keep the compiler from moving LDS accesses across this point
 #define SF_WAVE_SYNC()                                  \
   do {                                                  \

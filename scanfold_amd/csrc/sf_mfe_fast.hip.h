@@ -548,7 +548,8 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
     X.vNIN = F->NIN[lk]; X.vIL = F->IL[lk]; X.vL1N = F->L1N[lk]; X.vBUL = F->BUL[lk];
   }
   // group and centre-based mapping inside the group: v = (tg + OFF) mod NG, cell i = v - d/2
-  const int grp = tid / NG, tg = tid - grp * NG;
+  const int grp = SF_WAVE_UNIFORM(tid / NG);  // a wave lies in one group: keep d, row slots, loop limits scalar
+  const int tg = tid - grp * NG;
   const int OFF = (NG > 64) ? (((W + 1) >> 1) - 32 + NG) & (NG - 1) : 0;
   const int v = (tg + OFF) & (NG - 1);
 

@@ -154,6 +154,7 @@ template <typename T>
 inline T atomicOr(T *p, T v) { T o = *p; *p = o | v; return o; }
 
 #define SF_WAVE_SYNC() sfemul::wave_barrier()
+#define SF_WAVE_UNIFORM(x) (x)
 
 /* dynamic shared memory */
 #define SF_DYN_SMEM(name) char *name = sfemul::g_blk->smem.data()

@@ -151,6 +151,10 @@ struct SfFastCtx {
 };
 
 #define SF_TIDX(t, a, b) ((t)*25 + (a)*5 + (b))
+// c scratch in device memory: row j (j >= 5) holds the cells (i, j), i = 1..j-4; small enough (13.6 kB per
+// workgroup at W=120) that the whole grid's scratch stays in L2 between the fill and the exterior pass
+#define SF_CGIDX(i, j) ((((j)-5) * ((j)-4)) / 2 + (i)-1)
+#define SF_CG_ENTRIES(W) ((((W)-4) * ((W)-3)) / 2 + 8)
 
 // Size-dependent terms (loop initiation, asymmetry) are the same for every lane.  Each wave keeps the four
 // tables spread over the lanes of four VGPRs (lane k holds entry k) and fetches entry k with v_readlane:
@@ -292,7 +296,7 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
   } else {
     X.CI[rbd] = SF_INF16; X.C1N[rbd] = SF_INF16; X.CB[rbd] = SF_INF16;
   }
-  X.cg[(j - 1) * W + i0] = (int16_t)c;  // row j, column i: the exterior pass reads rows coalesced
+  X.cg[SF_CGIDX(i, j)] = (int16_t)c;  // row j, column i: the exterior pass reads rows coalesced
   // fML[i,j]: the two neighbours on diagonal d-1 are final only for the even-diagonal group (see the kernel)
   if (final_fml && d > SFD_TURN + 1) {
     const int fb = FBASE(d - 1);
@@ -370,7 +374,7 @@ __device__ inline int sf_fast_traceback(const SfFastCtx &X, const int32_t *f5s, 
   const int W = X.W;
   const uint8_t *S = X.S;
   const SfDevParams *D = X.D;
-#define TC(i, j) ((int)X.cg[((j)-1) * W + (i)-1])
+#define TC(i, j) ((int)X.cg[SF_CGIDX(i, j)])
 #define TF(i, j) (((j) - (i) < SFD_TURN + 1) ? SF_INF16 : (int)X.fML[FBASE((j) - (i)) + (i)-1])
 #define TPAIR(i, j) ((int)X.tPair[S[i] * 8 + S[j]])
   for (int x = lane; x < W; x += 64) dbL[x] = '.';
@@ -534,7 +538,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
   int16_t *tExt = (int16_t *)(smem + Lo.off_ci + (((W + 1) * 4 + 3) & ~3));
 
   const int tid = threadIdx.x;
-  X.cg = cg_all + (size_t)blockIdx.x * W * W;  // c by (row j, column i) for the exterior pass / traceback
+  X.cg = cg_all + (size_t)blockIdx.x * SF_CG_ENTRIES(W);  // c by (row j, column i), triangular
   // parameter tables -> LDS, once per workgroup
   for (int x = tid; x < 200; x += NT) {
     tab[x] = F->mmI[x]; tab[200 + x] = F->mm1n[x]; tab[400 + x] = F->mm23[x]; tab[600 + x] = F->mmM[x];
@@ -624,7 +628,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
 #pragma unroll
           for (int q = 0; q < NQ; q++) {
             const int i = lane + 64 * q + 1, j = j0 + k;
-            cbuf[k][q] = (j <= W && i <= W) ? (int)X.cg[(j - 1) * W + i - 1] : SF_INF16;
+            cbuf[k][q] = (j <= W && i + SFD_TURN + 1 <= j) ? (int)X.cg[SF_CGIDX(i, j)] : SF_INF16;
           }
 #pragma unroll
         for (int k = 0; k < RB; k++) {
@@ -702,7 +706,7 @@ static inline void sf_fast_geometry(int W, int n_cu, int n, int *grid, int *thre
   *grid = (int)gsz;
   *threads = nt;
   *lds = (size_t)L.total;
-  *scratch = (size_t)gsz * W * W * sizeof(int16_t);
+  *scratch = (size_t)gsz * SF_CG_ENTRIES(W) * sizeof(int16_t);
 }
 
 template <typename... A>

@@ -114,7 +114,7 @@ struct SfFastLayout {
   int off_ci, off_c1n, off_cb, off_dml, off_tab, off_red, off_flag, off_S;
   int total;
 };
-#define SF_FAST_TAB_BYTES (5 * 400 + 128 + 80 + 80 + 64)
+#define SF_FAST_TAB_BYTES (5 * 400 + 128 + 80 + 80 + 64 + 4 * 64)
 static inline __host__ __device__ SfFastLayout sf_fast_layout(int W) {
   SfFastLayout L;
   int tri = (W - 4) * W - (W * (W - 1) / 2 - 6);  // sum_{d=4}^{W-1} (W-d)
@@ -129,7 +129,7 @@ static inline __host__ __device__ SfFastLayout sf_fast_layout(int W) {
   L.off_cb = o; o += roll;
   L.off_dml = o; o += ((4 * RW + 1) & ~1) * 2;
   L.off_tab = o; o += SF_FAST_TAB_BYTES;
-  L.off_red = o; o += 8 * 4;
+  L.off_red = o;  // (unused)
   L.off_flag = o; o += 4;
   L.off_S = o; o += (W + 2 + 3) & ~3;
   L.total = o;
@@ -147,7 +147,7 @@ struct SfFastCtx {
   const SfFastParams *F;
   int16_t *cg;
   int W, TAU, MLbase, MLclosing, MLintern;
-  int vNIN, vIL, vL1N, vBUL;  // lane k of the wave holds table entry k (see SF_UNI)
+  const int16_t *uNIN, *uIL, *uL1N, *uBUL;  // size-dependent terms, LDS copies (uniform reads)
 };
 
 #define SF_TIDX(t, a, b) ((t)*25 + (a)*5 + (b))
@@ -156,14 +156,12 @@ struct SfFastCtx {
 #define SF_CGIDX(i, j) ((((j)-5) * ((j)-4)) / 2 + (i)-1)
 #define SF_CG_ENTRIES(W) ((((W)-4) * ((W)-3)) / 2 + 8)
 
-// Size-dependent terms (loop initiation, asymmetry) are the same for every lane.  Each wave keeps the four
-// tables spread over the lanes of four VGPRs (lane k holds entry k) and fetches entry k with v_readlane:
-// no memory access and no wait in the unrolled candidate code.
-#ifdef SF_EMUL
-#define SF_UNI(vreg, table, k) ((table)[k])
-#else
-#define SF_UNI(vreg, table, k) __builtin_amdgcn_readlane((vreg), (k))
-#endif
+// Size-dependent terms (loop initiation, asymmetry) are the same for every lane: they are read from small LDS
+// tables with a wave-uniform address (a broadcast read).  (Keeping them spread over the lanes of a VGPR and
+// fetching with v_readlane is NOT safe here: under the 128-VGPR cap such a register can be spilled and
+// reloaded while only some lanes are active, and the inactive lanes' entries are then lost — observed on
+// MI355X as wrong minima in a variant of this kernel.)
+#define SF_UNI(tab, k) ((int)(tab)[k])
 
 // One anti-diagonal for one thread.  H: this parity's per-size minima of the generic candidates of the
 // enclosed cell (i+1, j-1) on entry, of (i, j) on exit.  slot2 = (d-2) mod NR, slotd = d mod NR.
@@ -191,15 +189,15 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
   for (int u = 30; u >= 6; --u) {
     if (!G || u <= umax) {
       const int16_t *row = X.CI + ROW(u) + i0;
-      const int e = sfd_min(row[3], row[u - 1]) + SF_UNI(X.vNIN, X.F->NIN, u - 4);  // u1 = 2 and u2 = 2
+      const int e = sfd_min(row[3], row[u - 1]) + SF_UNI(X.uNIN, u - 4);  // u1 = 2 and u2 = 2
       H[u - 4] = sfd_min(e, H[u - 6]);
     }
   }
   if (!G || umax >= 5) {
     const int16_t *row = X.CI + ROW(5) + i0;
-    H[1] = sfd_min(row[3], row[4]) + SF_UNI(X.vNIN, X.F->NIN, 1);
+    H[1] = sfd_min(row[3], row[4]) + SF_UNI(X.uNIN, 1);
   }
-  if (!G || umax >= 4) H[0] = X.CI[ROW(4) + i0 + 3] + SF_UNI(X.vNIN, X.F->NIN, 0);
+  if (!G || umax >= 4) H[0] = X.CI[ROW(4) + i0 + 3] + SF_UNI(X.uNIN, 0);
 #endif
 
   // ---- pass 2 (pairable cells): c[i,j] ----
@@ -219,7 +217,7 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
         e = sfd_min(e, X.CB[ROW(0) + i0 + 1] - (t2r > 2 ? TAU : 0) + st[t2r]);
       }
       if (!G || umax >= 1) {  // one-nucleotide bulges keep the stack
-        const int b1 = SF_UNI(X.vBUL, X.F->BUL, 1);
+        const int b1 = SF_UNI(X.uBUL, 1);
         const int16_t *row = X.CB + ROW(1) + i0;
         const int ta = sfd_rtype(X.tPair[si1 * 8 + S[j - 2]]);  // (i+1, j-2)
         e = sfd_min(e, row[1] - (ta > 2 ? TAU : 0) + b1 + st[ta]);
@@ -257,9 +255,9 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
       for (int u = 2; u <= 30; ++u) {
         if (!G || u <= umax) {
           const int rw = ROW(u) + i0;
-          gb = sfd_min(gb, sfd_min(X.CB[rw + 1], X.CB[rw + 1 + u]) + SF_UNI(X.vBUL, X.F->BUL, u));
-          if (u >= 4) g1 = sfd_min(g1, sfd_min(X.C1N[rw + 2], X.C1N[rw + u]) + SF_UNI(X.vL1N, X.F->L1N, u - 1));
-          if (u >= 6) gg = sfd_min(gg, H[u - 4] + SF_UNI(X.vIL, X.F->IL, u));
+          gb = sfd_min(gb, sfd_min(X.CB[rw + 1], X.CB[rw + 1 + u]) + SF_UNI(X.uBUL, u));
+          if (u >= 4) g1 = sfd_min(g1, sfd_min(X.C1N[rw + 2], X.C1N[rw + u]) + SF_UNI(X.uL1N, u - 1));
+          if (u >= 6) gg = sfd_min(gg, H[u - 4] + SF_UNI(X.uIL, u));
         }
       }
 #endif
@@ -548,8 +546,12 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
   for (int x = tid; x < 40; x += NT) { tab[1064 + x] = F->d5[x]; tab[1104 + x] = F->d3[x]; }
 
   {
-    const int lk = tid & 31;
-    X.vNIN = F->NIN[lk]; X.vIL = F->IL[lk]; X.vL1N = F->L1N[lk]; X.vBUL = F->BUL[lk];
+    int16_t *uni = tab + 1144 + 32;  // after the 64-byte pair table
+    X.uNIN = uni; X.uIL = uni + 32; X.uL1N = uni + 64; X.uBUL = uni + 96;
+    for (int x = tid; x < 32; x += NT) {
+      uni[x] = (int16_t)sfd_min(F->NIN[x], 32000); uni[32 + x] = (int16_t)sfd_min(F->IL[x], 32000);
+      uni[64 + x] = (int16_t)sfd_min(F->L1N[x], 32000); uni[96 + x] = (int16_t)sfd_min(F->BUL[x], 32000);
+    }
   }
   // group and centre-based mapping inside the group: v = (tg + OFF) mod NG, cell i = v - d/2
   const int grp = SF_WAVE_UNIFORM(tid / NG);  // a wave lies in one group: keep d, row slots, loop limits scalar

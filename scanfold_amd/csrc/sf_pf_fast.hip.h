@@ -9,7 +9,7 @@
 //    (qbI / obI = qb / ob pre-multiplied by the pair's own interior mismatch weight), 6 table reads per loop
 //    size instead of one per (u1,u2);
 //  * every O(W) multiloop sum is indexed by diagonal so that the threads of a wave read consecutive addresses.
-// Tables are FP64, diagonal-major T(d,i), in device memory (L2-resident: 13 tables x W x (W+1) doubles per
+// Tables are FP64, triangular diagonal-major T(d,i), in device memory (13 tables x W(W+1)/2 doubles per
 // workgroup).  Sums are re-associated with respect to the oracle, so results agree to ~1e-12 relative.
 #pragma once
 #include "sf_energy.h"
@@ -17,7 +17,8 @@
 #include <type_traits>
 
 #define SF_PFF_NTABLES 13
-#define SF_PFF_SCRATCH_DOUBLES(W) (SF_PFF_NTABLES * (size_t)(W) * ((W) + 1))
+#define SF_PFF_TABLE_DOUBLES(W) ((size_t)(W) * ((W) + 1) / 2 + 8)
+#define SF_PFF_SCRATCH_DOUBLES(W) (SF_PFF_NTABLES * SF_PFF_TABLE_DOUBLES(W))
 #define SF_PFF_MAXW 256
 
 struct SfPfTabs {
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(NT) void sf_pf_fast_kernel(const uint8_t *__restric
   __shared__ double red[8];
   const int tid = threadIdx.x;
   const int W1 = W + 1;
-  const size_t TS = (size_t)W * W1;
+  const size_t TS = SF_PFF_TABLE_DOUBLES(W);
   SfPfTabs T;
   {
     double *b = scratch + (size_t)blockIdx.x * SF_PFF_SCRATCH_DOUBLES(W);
@@ -45,7 +46,8 @@ __global__ __launch_bounds__(NT) void sf_pf_fast_kernel(const uint8_t *__restric
     T.OB = b + 6 * TS; T.OBI = b + 7 * TS; T.OB1N = b + 8 * TS; T.OBB = b + 9 * TS; T.OBW = b + 10 * TS;
     T.A0 = b + 11 * TS; T.A1 = b + 12 * TS;
   }
-#define PT(tab, d, i) tab[(size_t)(d)*W1 + (i)]
+// triangular, diagonal-major: diagonal d holds the cells i = 1..W-d
+#define PT(tab, d, i) tab[(d)*W - ((d) * ((d)-1)) / 2 + (i)-1]
   const double *mlb = X->mlbase_pow;
   const int OFF = (((W + 1) >> 1) - 32 + NT) & (NT - 1);
   const int v = (tid + OFF) & (NT - 1);
@@ -56,7 +58,7 @@ __global__ __launch_bounds__(NT) void sf_pf_fast_kernel(const uint8_t *__restric
     __syncthreads();
     for (int x = tid; x < W; x += NT) S[x + 1] = sf_encode_nt(src[x]);
     if (tid == 0) { S[0] = 0; S[W + 1] = 0; }
-    for (size_t x = tid; x < (size_t)4 * W1 && x < TS; x += NT) {
+    for (size_t x = tid; x < (size_t)4 * W && x < TS; x += NT) {
       T.QB[x] = 0.0; T.QBI[x] = 0.0; T.QB1N[x] = 0.0; T.QBB[x] = 0.0; T.QM[x] = 0.0; T.QM1[x] = 0.0;
     }
     __syncthreads();

@@ -504,6 +504,14 @@ int sf_set_kernel_mode(int mode) {
   return SF_OK;
 }
 
+#ifdef SF_STAMP
+int sf_debug_stamps(unsigned long long *out) {  // diagnostic build only
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(sf_stamp_acc), sizeof(unsigned long long) * 64));
+  return SF_OK;
+}
+#endif
+
 int sf_prof_reset(void) {
   if (!g.init) return SF_ERR_NOT_INIT;
   HIPCHK(hipDeviceSynchronize());

@@ -8,6 +8,8 @@
 #define SF_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
 #define SF_LAUNCH(kern, grid, block, shmem, stream, ...) \
   hipLaunchKernelGGL(kern, dim3(grid), dim3(block), shmem, stream, __VA_ARGS__)
+// scheduling hint: the next `n` instructions of class `mask` (0x100 = LDS read, 0x2 = VALU) form one group
+#define SF_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier((mask), (n), 0)
 // a value that is the same in every lane of the wave: tell the compiler (keeps derived index math scalar)
 #define SF_WAVE_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 // lanes of one wave exchanging data through LDS: keep the compiler from moving LDS accesses across this point

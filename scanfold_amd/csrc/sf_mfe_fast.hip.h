@@ -185,12 +185,33 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
 
   // ---- pass 1 (every cell): per-size minima of the generic interior candidates ----
 #ifndef SF_ABL_PASS1
+  if (G) {
 #pragma unroll
-  for (int u = 30; u >= 6; --u) {
-    if (!G || u <= umax) {
-      const int16_t *row = X.CI + ROW(u) + i0;
-      const int e = sfd_min(row[3], row[u - 1]) + SF_UNI(X.uNIN, u - 4);  // u1 = 2 and u2 = 2
-      H[u - 4] = sfd_min(e, H[u - 6]);
+    for (int u = 30; u >= 6; --u) {
+      if (u <= umax) {
+        const int16_t *row = X.CI + ROW(u) + i0;
+        const int e = sfd_min(row[3], row[u - 1]) + SF_UNI(X.uNIN, u - 4);  // u1 = 2 and u2 = 2
+        H[u - 4] = sfd_min(e, H[u - 6]);
+      }
+    }
+  } else {
+    // all sizes exist: fetch in batches (the LDS queue holds 15 reads per wave), then update in descending u
+#pragma unroll
+    for (int ub = 30; ub >= 6; ub -= 5) {
+      int e1[5], e2[5], nn[5];
+#pragma unroll
+      for (int k = 0; k < 5; k++) {
+        const int u = ub - k;
+        const int16_t *row = X.CI + ROW(u) + i0;
+        e1[k] = row[3];
+        e2[k] = row[u - 1];
+        nn[k] = SF_UNI(X.uNIN, u - 4);
+      }
+#pragma unroll
+      for (int k = 0; k < 5; k++) {
+        const int u = ub - k;
+        H[u - 4] = sfd_min(sfd_min(e1[k], e2[k]) + nn[k], H[u - 6]);
+      }
     }
   }
   if (!G || umax >= 5) {
@@ -251,13 +272,40 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
       // bulges (size u >= 2), 1 x n loops (total size u >= 4) and the generic minima, one rolling row per u
       int gb = SF_FAST_BIG, g1 = SF_FAST_BIG, gg = SF_FAST_BIG;
 #ifndef SF_ABL_PASS2
+      if (G) {
 #pragma unroll
-      for (int u = 2; u <= 30; ++u) {
-        if (!G || u <= umax) {
-          const int rw = ROW(u) + i0;
-          gb = sfd_min(gb, sfd_min(X.CB[rw + 1], X.CB[rw + 1 + u]) + SF_UNI(X.uBUL, u));
-          if (u >= 4) g1 = sfd_min(g1, sfd_min(X.C1N[rw + 2], X.C1N[rw + u]) + SF_UNI(X.uL1N, u - 1));
-          if (u >= 6) gg = sfd_min(gg, H[u - 4] + SF_UNI(X.uIL, u));
+        for (int u = 2; u <= 30; ++u) {
+          if (u <= umax) {
+            const int rw = ROW(u) + i0;
+            gb = sfd_min(gb, sfd_min(X.CB[rw + 1], X.CB[rw + 1 + u]) + SF_UNI(X.uBUL, u));
+            if (u >= 4) g1 = sfd_min(g1, sfd_min(X.C1N[rw + 2], X.C1N[rw + u]) + SF_UNI(X.uL1N, u - 1));
+            if (u >= 6) gg = sfd_min(gg, H[u - 4] + SF_UNI(X.uIL, u));
+          }
+        }
+      } else {
+        // batches of two sizes = 14 LDS reads in flight
+#pragma unroll
+        for (int ub = 2; ub <= 30; ub += 2) {
+          int b1[2], b2[2], n1[2], n2[2], tb[2], tn[2], ti[2];
+#pragma unroll
+          for (int k = 0; k < 2; k++) {
+            const int u = ub + k;
+            if (u <= 30) {
+              const int rw = ROW(u) + i0;
+              b1[k] = X.CB[rw + 1]; b2[k] = X.CB[rw + 1 + u]; tb[k] = SF_UNI(X.uBUL, u);
+              if (u >= 4) { n1[k] = X.C1N[rw + 2]; n2[k] = X.C1N[rw + u]; tn[k] = SF_UNI(X.uL1N, u - 1); }
+              if (u >= 6) ti[k] = SF_UNI(X.uIL, u);
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < 2; k++) {
+            const int u = ub + k;
+            if (u <= 30) {
+              gb = sfd_min(gb, sfd_min(b1[k], b2[k]) + tb[k]);
+              if (u >= 4) g1 = sfd_min(g1, sfd_min(n1[k], n2[k]) + tn[k]);
+              if (u >= 6) gg = sfd_min(gg, H[u - 4] + ti[k]);
+            }
+          }
         }
       }
 #endif
@@ -502,6 +550,12 @@ __device__ inline int sf_fast_traceback(const SfFastCtx &X, const int32_t *f5s, 
 // the odd ones.  c[.,.] of diagonal d+1 does not depend on diagonal d (an enclosed pair spans at most d-1, the
 // multiloop split of d+1 reads fML spans <= d-3), only fML[d+1] needs its two neighbours on d — so the pair
 // (d, d+1) is computed concurrently by the two groups, then group 1 adds the neighbour term after one barrier.
+#ifdef SF_STAMP
+// diagnostic build only: per-wave cycle totals of block 0 (cell work / barrier 1 / odd finalize / barrier 2 / exterior)
+__device__ unsigned long long sf_stamp_acc[8][8];
+#define SF_T() __builtin_amdgcn_s_memtime()
+#endif
+
 template <int NG>
 __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_kernel(const uint8_t *__restrict__ seqs, int n, int W,
                                                              const SfDevParams *__restrict__ D,
@@ -578,6 +632,9 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
       const int i = v - (d >> 1);
       const bool valid = (d < W) && (i >= 1) && (i + d <= W);
       int fpart = SF_FAST_BIG;
+#ifdef SF_STAMP
+      const unsigned long long t0 = SF_T();
+#endif
 #ifdef SF_ABL_CELL
       if (0) {
 #else
@@ -586,7 +643,13 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
         if (d0 < SFD_MAXLOOP + 6) sf_fast_cell<true>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fpart);
         else sf_fast_cell<false>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fpart);
       }
+#ifdef SF_STAMP
+      const unsigned long long t1 = SF_T();
+#endif
       __syncthreads();
+#ifdef SF_STAMP
+      const unsigned long long t2 = SF_T();
+#endif
       if (grp == 1 && valid) {  // fML[i,j] on the odd diagonal: add the neighbours on diagonal d-1, now final
         const int i0 = i - 1;
         const int fb = FBASE(d - 1);
@@ -594,7 +657,19 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
         if (f < SF_FAST_OVF) ovf = 1;
         X.fML[FBASE(d) + i0] = (int16_t)(f > SF_FAST_THRESH ? SF_INF16 : f);
       }
+#ifdef SF_STAMP
+      const unsigned long long t3 = SF_T();
+#endif
       __syncthreads();
+#ifdef SF_STAMP
+      if (blockIdx.x == 0 && (tid & 63) == 0) {
+        const unsigned long long t4 = SF_T();
+        const int w = tid >> 6;
+        sf_stamp_acc[w][0] += t1 - t0; sf_stamp_acc[w][1] += t2 - t1; sf_stamp_acc[w][2] += t3 - t2;
+        sf_stamp_acc[w][3] += t4 - t3; sf_stamp_acc[w][5] += 1;
+        if (d0 >= 56) { sf_stamp_acc[w][6] += t1 - t0; sf_stamp_acc[w][7] += 1; }
+      }
+#endif
       slot2 += 2; if (slot2 >= SF_FAST_NR) slot2 -= SF_FAST_NR;
       slotd += 2; if (slotd >= SF_FAST_NR) slotd -= SF_FAST_NR;
     }
@@ -602,6 +677,9 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
     // ---- exterior loop f5[j] = min(f5[j-1], min_i f5[i-1] + c[i,j] + ExtLoop(i,j)) : wave 0 only ----
     // lane l owns i = l+1, l+65, ...; f5[i-1] sits in its registers, c rows stream from device memory
     // (one row ahead), the minimum over i is a wave butterfly.  No workgroup barrier inside the loop.
+#ifdef SF_STAMP
+    const unsigned long long tf0 = SF_T();
+#endif
     if (ovf) flag[0] = 1;
     for (int x = tid; x < 200; x += NT) tExt[x] = F->mmExt[x];
     __syncthreads();
@@ -632,34 +710,46 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
             const int i = lane + 64 * q + 1, j = j0 + k;
             cbuf[k][q] = (j <= W && i + SFD_TURN + 1 <= j) ? (int)X.cg[SF_CGIDX(i, j)] : SF_INF16;
           }
+        // f5[j] needs f5[i-1] only for i <= j-4, so four consecutive j are independent up to the running
+        // minimum: their candidate minima (and wave reductions) are computed side by side, then chained
 #pragma unroll
-        for (int k = 0; k < RB; k++) {
-          const int j = j0 + k;
-          if (j <= W) {
-            const int sj = S[j], sj1 = S[j + 1];
+        for (int kb = 0; kb < RB; kb += 4) {
+          int vals[4];
+#pragma unroll
+          for (int kk = 0; kk < 4; kk++) {
+            const int k = kb + kk, j = j0 + k;
             int val = SF_FAST_BIG * 2;
+            if (j <= W) {
+              const int sj = S[j], sj1 = S[j + 1];
 #pragma unroll
-            for (int q = 0; q < NQ; q++) {
-              const int i = lane + 64 * q + 1;
-              if (i + SFD_TURN + 1 <= j) {
-                const int type = tPair[si[q] * 8 + sj];
-                if (type) {
-                  int ext;
-                  if (i > 1 && j < W) ext = tExt[SF_TIDX(type, sim1[q], sj1)];
-                  else if (i > 1) ext = X.tD5[type * 5 + sim1[q]];
-                  else if (j < W) ext = X.tD3[type * 5 + sj1];
-                  else ext = 0;
-                  val = sfd_min(val, f5r[q] + cbuf[k][q] + ext + (type > 2 ? X.TAU : 0));
+              for (int q = 0; q < NQ; q++) {
+                const int i = lane + 64 * q + 1;
+                if (i + SFD_TURN + 1 <= j) {
+                  const int type = tPair[si[q] * 8 + sj];
+                  if (type) {
+                    int ext;
+                    if (i > 1 && j < W) ext = tExt[SF_TIDX(type, sim1[q], sj1)];
+                    else if (i > 1) ext = X.tD5[type * 5 + sim1[q]];
+                    else if (j < W) ext = X.tD3[type * 5 + sj1];
+                    else ext = 0;
+                    val = sfd_min(val, f5r[q] + cbuf[k][q] + ext + (type > 2 ? X.TAU : 0));
+                  }
                 }
               }
             }
-            val = sf_wave_min(val);
-            const int f5j = sfd_min(f5prev, val);
-            f5prev = f5j;
-            if (lane == 0) f5s[j] = f5j;
+            vals[kk] = sf_wave_min(val);
+          }
 #pragma unroll
-            for (int q = 0; q < NQ; q++)
-              if (lane + 64 * q == j) f5r[q] = f5j;
+          for (int kk = 0; kk < 4; kk++) {
+            const int j = j0 + kb + kk;
+            if (j <= W) {
+              const int f5j = sfd_min(f5prev, vals[kk]);
+              f5prev = f5j;
+              if (lane == 0) f5s[j] = f5j;
+#pragma unroll
+              for (int q = 0; q < NQ; q++)
+                if (lane + 64 * q == j) f5r[q] = f5j;
+            }
           }
         }
       }
@@ -684,6 +774,9 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
         if (bad && lane == 0) atomicOr(status, 1);
       }
     }
+#ifdef SF_STAMP
+    if (blockIdx.x == 0 && (tid & 63) == 0) sf_stamp_acc[tid >> 6][4] += SF_T() - tf0;
+#endif
   }
 #undef FBASE
 }

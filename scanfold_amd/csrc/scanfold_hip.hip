@@ -5,6 +5,7 @@
 // on one HIP stream.  No CPU compute path exists in this file: without a GPU sf_init fails.
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -273,6 +274,7 @@ int sf_init(int device_ordinal) {
   HIPCHK(hipMalloc((void **)&g.dX, sizeof(SfDevParamsPF)));
   HIPCHK(hipMalloc((void **)&g.dF, sizeof(SfFastParams)));
   HIPCHK(sf_fast_configure());
+  if (const char *pb = getenv("SCANFOLD_PF_BLOCKS_PER_CU")) g.pf_blocks_per_cu = atoi(pb) > 0 ? atoi(pb) : 4;
   const char *ff = getenv("SCANFOLD_FORCE_FULL");
   g.force_full = (ff && ff[0] == '1');
   g.init = true;

@@ -240,6 +240,7 @@ __global__ __launch_bounds__(NT) void sf_pf_fast_kernel(const uint8_t *__restric
             // special loops; (kk,l) is the enclosing pair, its type tk, its inner neighbours S[kk+1], S[l-1]
 #define OBV(kk, l) (((kk) >= 1 && (l) <= W) ? PT(T.OB, (l) - (kk), (kk)) : 0.0)
 #define TK(kk, l) (((kk) >= 1 && (l) <= W) ? D->pair[S[kk]][S[l]] : 0)
+#define SS(x) S[(x) < 0 ? 0 : ((x) > W + 1 ? W + 1 : (x))]  /* neighbours of pairs that may not exist */
             {
               const int tk = TK(i - 1, j + 1);
               o += OBV(i - 1, j + 1) * X->stack[tk][rt];
@@ -254,22 +255,23 @@ __global__ __launch_bounds__(NT) void sf_pf_fast_kernel(const uint8_t *__restric
             }
             {
               const int ta = TK(i - 2, j + 3);  // u1 = 1, u2 = 2
-              o += OBV(i - 2, j + 3) * X->int21[ta][rt][S[i - 1]][sq1][S[j + 2]];
+              o += OBV(i - 2, j + 3) * X->int21[ta][rt][S[i - 1]][sq1][SS(j + 2)];
               const int tb = TK(i - 3, j + 2);  // u1 = 2, u2 = 1
-              o += OBV(i - 3, j + 2) * X->int21[rt][tb][sq1][S[i - 2]][sp1];
+              o += OBV(i - 3, j + 2) * X->int21[rt][tb][sq1][SS(i - 2)][sp1];
             }
             {
               const int tk = TK(i - 3, j + 3);
-              o += OBV(i - 3, j + 3) * X->int22[tk][rt][S[i - 2]][sp1][sq1][S[j + 2]];
+              o += OBV(i - 3, j + 3) * X->int22[tk][rt][SS(i - 2)][sp1][sq1][SS(j + 2)];
             }
             {
               const double m23 = X->internal_loop[5] * X->ninio[1] * X->mismatch23I[rt][sq1][sp1];
               const int ta = TK(i - 3, j + 4), tb = TK(i - 4, j + 3);
-              o += m23 * (OBV(i - 3, j + 4) * X->mismatch23I[ta][S[i - 2]][S[j + 3]] +
-                          OBV(i - 4, j + 3) * X->mismatch23I[tb][S[i - 3]][S[j + 2]]);
+              o += m23 * (OBV(i - 3, j + 4) * X->mismatch23I[ta][SS(i - 2)][SS(j + 3)] +
+                          OBV(i - 4, j + 3) * X->mismatch23I[tb][SS(i - 3)][SS(j + 2)]);
             }
 #undef OBV
 #undef TK
+#undef SS
             double gb = 0.0, g1 = 0.0, gg = 0.0;
 #pragma unroll
             for (int u = 2; u <= 30; ++u)

@@ -36,29 +36,28 @@ def synth_transcript(L, seed):
 
 def cpu_baseline(eng, seq, W, step, r, kind, seed, budget_s=15.0):
     """The oracle (a CPU port of the ViennaRNA-shaped path; see oracle/sf_oracle.c) on a bounded sample of the
-    same workload, all host cores via OpenMP for the r+1 energy folds.  Baseline only — never the product."""
+    same workload: per window 1 MFE + traceback, 1 partition function and r+1 MFE folds, one OpenMP thread per
+    window on every host core.  Baseline only — never the product."""
     from oracle import oracle
     from scanfold_amd import params
     oracle.build()
     oracle.set_params(params.default_params())
     cores = os.cpu_count() or 1
-    # calibrate on 2 windows, then size the sample for ~budget_s
+
     def run(n_win):
         rows = np.frombuffer(b"NACGU", dtype=np.uint8)[eng.shuffle_windows(seq, W, step, 0, n_win, r, kind, seed)]
         t0 = time.perf_counter()
-        oracle.mfe_batch(rows, nthreads=cores)
-        for w in range(n_win):
-            frag = seq[w * step:w * step + W]
-            oracle.mfe(frag)
-            oracle.pf(frag)
+        oracle.scan_windows(rows, n_win, r, nthreads=cores)
         return time.perf_counter() - t0
-    t2 = run(2)
-    n = int(max(4, min(2000, budget_s / max(t2 / 2, 1e-6))))
+    n0 = max(cores, 8)
+    t0 = run(n0)
+    n = int(max(n0, min(20000, n0 * budget_s / max(t0, 1e-6))))
+    n = (n // cores) * cores or n0
     t = run(n)
     return dict(value=n / t, unit="windows/s", cores=cores, kind="port",
-                sample="first %d windows of the workload (each: %d MFE folds via OpenMP on %d threads + 1 traceback "
-                       "+ 1 partition function, single-threaded), %.1f s of CPU time; oracle/sf_oracle.c, not "
-                       "ViennaRNA (absent)" % (n, r + 1, cores, t))
+                sample="first %d windows of the workload, one OpenMP thread per window on %d threads (each window: "
+                       "1 MFE + traceback, 1 partition function, %d MFE folds), %.1f s wall; oracle/sf_oracle.c, "
+                       "not ViennaRNA (absent)" % (n, cores, r + 1, t))
 
 
 def main():

@@ -34,6 +34,8 @@ def lib():
                                 ctypes.POINTER(ctypes.c_longlong)]
         L.sfo_pf.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.c_void_p,
                              ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+        L.sfo_scan_windows.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         _lib = L
     return _lib
 
@@ -104,3 +106,20 @@ def pf(seq, want_bpp=False):
     if rc:
         raise RuntimeError("sfo_pf rc=%d" % rc)
     return dict(dG=dG.value, centroid=cen.value.decode(), centroid_dist=cd.value, mean_bp_dist=mbd.value, bpp=bpp)
+
+
+def scan_windows(rows, n_win, r, nthreads=0):
+    """rows: uint8 ASCII (n_win*(r+1), W), row 0 of each window native.  Whole per-window job, one OpenMP thread
+    per window.  -> dict(energies (n_win, r+1), structure, centroid, ens_div)"""
+    arr = np.ascontiguousarray(rows, dtype=np.uint8)
+    W = arr.shape[1]
+    en = np.empty((n_win, r + 1), dtype=np.int32)
+    db = np.zeros((n_win, W + 1), dtype=np.uint8)
+    cen = np.zeros((n_win, W + 1), dtype=np.uint8)
+    ed = np.zeros(n_win)
+    rc = lib().sfo_scan_windows(arr.ctypes.data_as(ctypes.c_char_p), n_win, r, W, en.ctypes.data, db.ctypes.data,
+                                cen.ctypes.data, ed.ctypes.data, nthreads)
+    if rc:
+        raise RuntimeError("sfo_scan_windows rc=%d" % rc)
+    return dict(energies=en, structure=[bytes(x[:W]).decode() for x in db],
+                centroid=[bytes(x[:W]).decode() for x in cen], ens_div=ed)

@@ -527,6 +527,32 @@ int sfo_mfe_batch(const char *seqs, int nseq, int W, int *out, int nthreads) {
   return 0;
 }
 
+int sfo_pf(const char *seq, int n, double *ensemble_dG, double *bpp_out, char *centroid, double *centroid_dist,
+           double *mean_bp_dist);
+
+/* The whole per-window job of ScanFold-Scan.py:382-423 for n_win windows, every window on its own OpenMP
+ * thread: rows = n_win*(r+1) sequences of W chars, row 0 of a window is the native one (MFE + traceback +
+ * partition function), rows 1..r its shuffles (MFE only).  Used as bench.py's CPU baseline. */
+int sfo_scan_windows(const char *rows, int n_win, int r, int W, int *energies, char *structures, char *centroids,
+                     double *ens_div, int nthreads) {
+  if (!have_params) return -10;
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+  (void)nthreads;
+  int bad = 0;
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int w = 0; w < n_win; w++) {
+    const char *base = rows + (size_t)w * (r + 1) * W;
+    int rc = sfo_mfe(base, W, &energies[(size_t)w * (r + 1)], structures + (size_t)w * (W + 1));
+    double cd;
+    rc |= sfo_pf(base, W, NULL, NULL, centroids + (size_t)w * (W + 1), &cd, &ens_div[w]);
+    for (int k = 1; k <= r; k++) rc |= sfo_mfe(base + (size_t)k * W, W, &energies[(size_t)w * (r + 1) + k], NULL);
+    if (rc) bad = 1;
+  }
+  return bad ? -1 : 0;
+}
+
 /* =================================== independent evaluator =================================== */
 static int make_pair_table(const char *db, int n, int *pt) {
   int *stk = (int *)malloc(sizeof(int) * (size_t)(n + 1));

@@ -218,6 +218,18 @@ def test_config3_size_independent_properties(gpu_engine, oracle):
     assert (again == full).all()
 
 
+def test_config5_shape_w200_r1000_slice(gpu_engine, oracle):
+    # BASELINE config 5 shape (W=200, 1000 shuffles, partition function) on a 6-window slice of the 30 kb transcript
+    seq = synth_transcript(30000, 3)
+    W, r, lo, n = 200, 1000, 777, 6
+    res = gpu_engine.scan(seq, W, 1, lo, n, r, _lib.SHUFFLE_DI, 99)
+    rows = ascii_rows(gpu_engine.shuffle_windows(seq, W, 1, lo, n, r, _lib.SHUFFLE_DI, 99))
+    ref = oracle.scan_windows(rows, n, r)
+    assert (res["energies"] == ref["energies"]).all()
+    assert res["structure"] == ref["structure"] and res["centroid"] == ref["centroid"]
+    assert np.abs(res["ens_div"] - ref["ens_div"]).max() < PF_TOL
+
+
 def test_planted_hairpin_gets_a_negative_zscore(gpu_engine):
     rng = np.random.default_rng(9)
     bg = "".join("ACGU"[k] for k in rng.choice(4, 400, p=[0.3, 0.2, 0.2, 0.3]))

@@ -169,8 +169,13 @@ struct SfFastCtx {
 // !G: all sizes 0..30 exist, the candidate code is one straight-line block the scheduler can pipeline.
 template <bool G>
 __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, const int i, const bool valid,
-                                             const int slot2, const int slotd, int (&H)[27], int &ovf,
+                                             const int slot2, const int slotd, uint32_t (&HP)[14], int &ovf,
                                              const bool final_fml, int &fpart) {
+// H[x] (x = size - 4) lives in the int16 halves of HP[x/2]: 14 registers instead of 27 under the 128-VGPR cap
+#define HGET(x) (((x)&1) ? ((int)HP[(x) >> 1] >> 16) : (int)(int16_t)(HP[(x) >> 1] & 0xffffu))
+#define HSET(x, v)                                                                                       \
+  HP[(x) >> 1] = ((x)&1) ? ((HP[(x) >> 1] & 0x0000ffffu) | ((uint32_t)(v) << 16))                         \
+                         : ((HP[(x) >> 1] & 0xffff0000u) | ((uint32_t)(v)&0xffffu))
   const int W = X.W, RW = W - 4;
   if (!valid) return;
   const int j = i + d, i0 = i - 1;
@@ -191,7 +196,7 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
       if (u <= umax) {
         const int16_t *row = X.CI + ROW(u) + i0;
         const int e = sfd_min(row[3], row[u - 1]) + SF_UNI(X.uNIN, u - 4);  // u1 = 2 and u2 = 2
-        H[u - 4] = sfd_min(e, H[u - 6]);
+        HSET(u - 4, sfd_min(e, HGET(u - 6)));
       }
     }
   } else {
@@ -210,15 +215,15 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
 #pragma unroll
       for (int k = 0; k < 5; k++) {
         const int u = ub - k;
-        H[u - 4] = sfd_min(sfd_min(e1[k], e2[k]) + nn[k], H[u - 6]);
+        HSET(u - 4, sfd_min(sfd_min(e1[k], e2[k]) + nn[k], HGET(u - 6)));
       }
     }
   }
   if (!G || umax >= 5) {
     const int16_t *row = X.CI + ROW(5) + i0;
-    H[1] = sfd_min(row[3], row[4]) + SF_UNI(X.uNIN, 1);
+    HSET(1, sfd_min(row[3], row[4]) + SF_UNI(X.uNIN, 1));
   }
-  if (!G || umax >= 4) H[0] = X.CI[ROW(4) + i0 + 3] + SF_UNI(X.uNIN, 0);
+  if (!G || umax >= 4) HSET(0, X.CI[ROW(4) + i0 + 3] + SF_UNI(X.uNIN, 0));
 #endif
 
   // ---- pass 2 (pairable cells): c[i,j] ----
@@ -279,7 +284,7 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
             const int rw = ROW(u) + i0;
             gb = sfd_min(gb, sfd_min(X.CB[rw + 1], X.CB[rw + 1 + u]) + SF_UNI(X.uBUL, u));
             if (u >= 4) g1 = sfd_min(g1, sfd_min(X.C1N[rw + 2], X.C1N[rw + u]) + SF_UNI(X.uL1N, u - 1));
-            if (u >= 6) gg = sfd_min(gg, H[u - 4] + SF_UNI(X.uIL, u));
+            if (u >= 6) gg = sfd_min(gg, HGET(u - 4) + SF_UNI(X.uIL, u));
           }
         }
       } else {
@@ -303,7 +308,7 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
             if (u <= 30) {
               gb = sfd_min(gb, sfd_min(b1[k], b2[k]) + tb[k]);
               if (u >= 4) g1 = sfd_min(g1, sfd_min(n1[k], n2[k]) + tn[k]);
-              if (u >= 6) gg = sfd_min(gg, H[u - 4] + ti[k]);
+              if (u >= 6) gg = sfd_min(gg, HGET(u - 4) + ti[k]);
             }
           }
         }
@@ -621,9 +626,9 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
     for (int x = tid; x < 4 * RW; x += NT) X.DMLr[x] = SF_INF16;  // diagonals 2,3 have no multiloop split
     __syncthreads();
     int ovf = 0;
-    int H[27];
+    uint32_t H[14];  // packed int16 pairs, see HGET/HSET
 #pragma unroll
-    for (int k = 0; k < 27; k++) H[k] = SF_FAST_BIG;
+    for (int k = 0; k < 14; k++) H[k] = (uint32_t)SF_INF16 | ((uint32_t)SF_INF16 << 16);
 
     // this thread's diagonal in the step that starts at the even diagonal d0 is d0 + grp
     int slot2 = (SFD_TURN + 1 + grp - 2) % SF_FAST_NR, slotd = (SFD_TURN + 1 + grp) % SF_FAST_NR;

@@ -230,6 +230,31 @@ def test_config5_shape_w200_r1000_slice(gpu_engine, oracle):
     assert np.abs(res["ens_div"] - ref["ens_div"]).max() < PF_TOL
 
 
+def test_edge_shapes(gpu_engine, oracle):
+    # L == W (one window), step larger than the remainder, r = 0 and r = 1, the smallest LDS-kernel width
+    seq = synth_transcript(120, 21)
+    res = gpu_engine.scan(seq, 120, 1, 0, 1, 0, _lib.SHUFFLE_DI, 1)
+    assert res["energies"].shape == (1, 1) and int(res["energies"][0, 0]) == oracle.mfe(seq)[1]
+    assert res["structure"][0] == oracle.mfe(seq)[0]
+    rows = scanmod.scan_record(seq + "ACGU" * 3, 120, 50, 1, "mono", 37, gpu_engine, seed=2)
+    assert len(rows) == 1 and rows[0].split("\t")[:2] == ["1", "120"]
+    seq16 = synth_transcript(400, 22)
+    res = gpu_engine.scan(seq16, 16, 3, 0, 129, 4, _lib.SHUFFLE_MONO, 3)
+    rows16 = ascii_rows(gpu_engine.shuffle_windows(seq16, 16, 3, 0, 129, 4, _lib.SHUFFLE_MONO, 3))
+    assert (res["energies"].reshape(-1) == oracle.mfe_batch(rows16)).all()
+    # a window containing N: device di-shuffle treats N as a fifth symbol, folds treat it as non-pairing
+    seqn = seq[:50] + "NNNN" + seq[54:]
+    res = gpu_engine.scan(seqn, 120, 1, 0, 1, 8, _lib.SHUFFLE_DI, 4)
+    rowsn = ascii_rows(gpu_engine.shuffle_windows(seqn, 120, 1, 0, 1, 8, _lib.SHUFFLE_DI, 4))
+    assert (res["energies"].reshape(-1) == oracle.mfe_batch(rowsn)).all()
+    for k in range(1, 9):
+        s = bytes(rowsn[k]).decode()
+        assert Counter(zip(s, s[1:])) == Counter(zip(seqn, seqn[1:])) and s.count("N") == 4
+    # empty batches are fine
+    assert len(gpu_engine.mfe_batch(np.zeros((0, 120), dtype=np.uint8))) == 0
+    assert gpu_engine.scan(seq, 120, 1, 0, 0, 5, _lib.SHUFFLE_DI, 1)["energies"].shape == (0, 6)
+
+
 def test_planted_hairpin_gets_a_negative_zscore(gpu_engine):
     rng = np.random.default_rng(9)
     bg = "".join("ACGU"[k] for k in rng.choice(4, 400, p=[0.3, 0.2, 0.2, 0.3]))

@@ -167,7 +167,7 @@ struct SfFastCtx {
 // enclosed cell (i+1, j-1) on entry, of (i, j) on exit.  slot2 = (d-2) mod NR, slotd = d mod NR.
 // G ("guarded"): d < 36, the loop-size limit d-6 is below MAXLOOP and every size is tested against it;
 // !G: all sizes 0..30 exist, the candidate code is one straight-line block the scheduler can pipeline.
-template <bool G>
+template <bool G, int WT>
 __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, const int i, const bool valid,
                                              const int slot2, const int slotd, uint32_t (&HP)[14], int &ovf,
                                              const bool final_fml, int &fpart) {
@@ -176,7 +176,7 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
 #define HSET(x, v)                                                                                       \
   HP[(x) >> 1] = ((x)&1) ? ((HP[(x) >> 1] & 0x0000ffffu) | ((uint32_t)(v) << 16))                         \
                          : ((HP[(x) >> 1] & 0xffff0000u) | ((uint32_t)(v)&0xffffu))
-  const int W = X.W, RW = W - 4;
+  const int W = WT ? WT : X.W, RW = W - 4;  // WT > 0: window width known at compile time (index math folds)
   if (!valid) return;
   const int j = i + d, i0 = i - 1;
   const uint8_t *S = X.S;
@@ -561,8 +561,8 @@ __device__ unsigned long long sf_stamp_acc[8][8];
 #define SF_T() __builtin_amdgcn_s_memtime()
 #endif
 
-template <int NG>
-__global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_kernel(const uint8_t *__restrict__ seqs, int n, int W,
+template <int NG, int WT>
+__global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_kernel(const uint8_t *__restrict__ seqs, int n, int Wrt,
                                                              const SfDevParams *__restrict__ D,
                                                              const SfFastParams *__restrict__ F,
                                                              int16_t *__restrict__ cg_all, int32_t *__restrict__ out,
@@ -570,6 +570,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
                                                              int trace_stride, char *__restrict__ db_out,
                                                              int *__restrict__ status) {
   constexpr int NT = 2 * NG;
+  const int W = WT ? WT : Wrt;
   SF_DYN_SMEM(smem);
   const SfFastLayout Lo = sf_fast_layout(W);
   const int RW = W - 4;
@@ -645,8 +646,8 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
 #else
       if (__ballot(valid)) {
 #endif
-        if (d0 < SFD_MAXLOOP + 6) sf_fast_cell<true>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fpart);
-        else sf_fast_cell<false>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fpart);
+        if (d0 < SFD_MAXLOOP + 6) sf_fast_cell<true, WT>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fpart);
+        else sf_fast_cell<false, WT>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fpart);
       }
 #ifdef SF_STAMP
       const unsigned long long t1 = SF_T();
@@ -787,9 +788,13 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
 }
 
 static inline hipError_t sf_fast_configure() {
-  hipError_t e = hipFuncSetAttribute((const void *)sf_mfe_fast_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipError_t e = hipFuncSetAttribute((const void *)sf_mfe_fast_kernel<128, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) return e;
-  return hipFuncSetAttribute((const void *)sf_mfe_fast_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  e = hipFuncSetAttribute((const void *)sf_mfe_fast_kernel<128, 120>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void *)sf_mfe_fast_kernel<256, 200>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute((const void *)sf_mfe_fast_kernel<256, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 // grid / LDS / scratch for n folds of W nt on a chip with n_cu CUs
@@ -809,8 +814,14 @@ static inline void sf_fast_geometry(int W, int n_cu, int n, int *grid, int *thre
   *scratch = (size_t)gsz * SF_CG_ENTRIES(W) * sizeof(int16_t);
 }
 
+// W = 120 is ScanFold's default window (ScanFold-Scan.py:37) and W = 200 is BASELINE config 5: they get
+// instantiations with the width folded in (less scalar index arithmetic, fewer spills); any other width runs
+// the generic instantiation
 template <typename... A>
-static inline void sf_fast_launch(int grid, int threads, size_t lds, hipStream_t st, A... args) {
-  if (threads == 256) SF_LAUNCH(sf_mfe_fast_kernel<128>, grid, 256, lds, st, args...);
-  else SF_LAUNCH(sf_mfe_fast_kernel<256>, grid, 512, lds, st, args...);
+static inline void sf_fast_launch(int grid, int threads, size_t lds, hipStream_t st, const uint8_t *seqs, int n, int W,
+                                  A... args) {
+  if (threads == 256 && W == 120) SF_LAUNCH((sf_mfe_fast_kernel<128, 120>), grid, 256, lds, st, seqs, n, W, args...);
+  else if (threads == 256) SF_LAUNCH((sf_mfe_fast_kernel<128, 0>), grid, 256, lds, st, seqs, n, W, args...);
+  else if (W == 200) SF_LAUNCH((sf_mfe_fast_kernel<256, 200>), grid, 512, lds, st, seqs, n, W, args...);
+  else SF_LAUNCH((sf_mfe_fast_kernel<256, 0>), grid, 512, lds, st, seqs, n, W, args...);
 }

@@ -25,7 +25,7 @@ def ascii_rows(codes):
 def test_fast_and_full_mfe_kernels_match_oracle(emul, oracle):
     emul.load_params(params.default_params())
     rng = np.random.default_rng(0)
-    for W, n in ((8, 8), (13, 10), (37, 8), (64, 6), (120, 4)):
+    for W, n in ((8, 8), (13, 10), (37, 8), (64, 6), (120, 4), (200, 2)):
         arr = random_seqs(rng, n, W)
         ref = oracle.mfe_batch(arr)
         emul.set_kernel_mode(0)

@@ -25,8 +25,8 @@ struct SfPfTabs {
   double *QB, *QBI, *QB1N, *QBB, *QM, *QM1, *OB, *OBI, *OB1N, *OBB, *OBW, *A0, *A1;
 };
 
-template <int NT>
-__global__ __launch_bounds__(NT) void sf_pf_fast_kernel(const uint8_t *__restrict__ seqs, int n, int row_stride, int W,
+template <int NT, int WT>
+__global__ __launch_bounds__(NT) void sf_pf_fast_kernel(const uint8_t *__restrict__ seqs, int n, int row_stride, int Wrt,
                                                         const SfDevParams *__restrict__ D,
                                                         const SfDevParamsPF *__restrict__ X,
                                                         double *__restrict__ scratch, double *__restrict__ ens_dG,
@@ -36,6 +36,7 @@ __global__ __launch_bounds__(NT) void sf_pf_fast_kernel(const uint8_t *__restric
   __shared__ double q5[SF_PFF_MAXW + 2];
   __shared__ double q3[SF_PFF_MAXW + 3];
   __shared__ double red[8];
+  const int W = WT ? WT : Wrt;  // WT > 0: width known at compile time
   const int tid = threadIdx.x;
   const int W1 = W + 1;
   const size_t TS = SF_PFF_TABLE_DOUBLES(W);
@@ -375,6 +376,8 @@ __global__ __launch_bounds__(NT) void sf_pf_fast_kernel(const uint8_t *__restric
 
 template <typename... A>
 static inline void sf_pf_fast_launch(int grid, int W, hipStream_t st, A... args) {
-  if (W <= 128) SF_LAUNCH(sf_pf_fast_kernel<128>, grid, 128, 0, st, args...);
-  else SF_LAUNCH(sf_pf_fast_kernel<256>, grid, 256, 0, st, args...);
+  if (W == 120) SF_LAUNCH((sf_pf_fast_kernel<128, 120>), grid, 128, 0, st, args...);
+  else if (W <= 128) SF_LAUNCH((sf_pf_fast_kernel<128, 0>), grid, 128, 0, st, args...);
+  else if (W == 200) SF_LAUNCH((sf_pf_fast_kernel<256, 200>), grid, 256, 0, st, args...);
+  else SF_LAUNCH((sf_pf_fast_kernel<256, 0>), grid, 256, 0, st, args...);
 }

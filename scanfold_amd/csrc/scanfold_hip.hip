@@ -17,6 +17,7 @@
 #include "sf_mfe_fast.hip.h"
 #include "sf_pf.hip.h"
 #include "sf_pf_fast.hip.h"
+#include "sf_pf_lds.hip.h"
 #include "sf_shuffle.hip.h"
 
 namespace {
@@ -45,6 +46,7 @@ struct Ctx {
   int64_t prof_launches = 0, prof_folds = 0;
   int force_full = 0;
   int fast_ok = 0;
+  int pf_kernel = 0;  // 0: LDS-resident kernel where it fits; 1: device-memory tables (SCANFOLD_PF_KERNEL=global)
   int pf_blocks_per_cu = 4;  // 256 VGPRs per thread: 2 waves per SIMD
 } g;
 
@@ -178,7 +180,12 @@ int launch_pf(const uint8_t *d_seqs, int n, int row_stride, int W, double *d_dG,
               double *d_cd, hipStream_t st) {
   if (n <= 0) return SF_OK;
   int grid = n < max_resident_blocks() ? n : max_resident_blocks();
-  if (W >= 16 && W <= SF_PFF_MAXW && !g.force_full) {
+  if (sf_pfl_supported(W) && !g.force_full && g.pf_kernel == 0) {
+    // every table of a fold in the LDS of one CU: one workgroup per CU
+    grid = n < g.n_cu ? n : g.n_cu;
+    sf_pf_lds_launch(grid, W, st, d_seqs, n, row_stride, W, (const SfDevParams *)g.dP, (const SfDevParamsPF *)g.dX,
+                     d_dG, d_mbd, d_cen, d_cd);
+  } else if (W >= 16 && W <= SF_PFF_MAXW && !g.force_full) {
     const int pf_blocks = g.n_cu * g.pf_blocks_per_cu;
     grid = n < pf_blocks ? n : pf_blocks;
     int rc = ensure(g.pf_scratch, (size_t)grid * SF_PFF_SCRATCH_DOUBLES(W) * sizeof(double));
@@ -274,6 +281,8 @@ int sf_init(int device_ordinal) {
   HIPCHK(hipMalloc((void **)&g.dX, sizeof(SfDevParamsPF)));
   HIPCHK(hipMalloc((void **)&g.dF, sizeof(SfFastParams)));
   HIPCHK(sf_fast_configure());
+  HIPCHK(sf_pfl_configure());
+  if (const char *pk = getenv("SCANFOLD_PF_KERNEL")) g.pf_kernel = (strcmp(pk, "global") == 0);
   if (const char *pb = getenv("SCANFOLD_PF_BLOCKS_PER_CU")) g.pf_blocks_per_cu = atoi(pb) > 0 ? atoi(pb) : 4;
   const char *ff = getenv("SCANFOLD_FORCE_FULL");
   g.force_full = (ff && ff[0] == '1');

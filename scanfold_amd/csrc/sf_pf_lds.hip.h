@@ -1,4 +1,4 @@
-// sf_pf_lds.hip.h — McCaskill partition function with every table resident in LDS (W <= SF_PFL_MAXW).
+// sf_pf_lds.hip.h — McCaskill partition function with every table resident in LDS (W <= ~120).
 //
 // Same mathematics and outputs as sf_pf_fast.hip.h / sf_pf.hip.h; replaces fc.pf() / fc.centroid() /
 // fc.mean_bp_distance() for the native windows (ScanFold-Scan.py:383-389).  What is different is the order of
@@ -11,8 +11,16 @@
 //      ob[k,l] += stem(k,l) sum_{i<k} ( qm[i+1,k-1] (R0[i]+R1[i]) + MLbase^(k-i-1) R1[i] )
 //    so only TWO full tables remain: qb (overwritten in place by ob during the outside pass; qb[k,l] is last
 //    read by the cell that replaces it) and qm.
-//  * a thread owns a centre s = i+j (cell (s-j, j) of column j), so the generic interior-loop sums are carried
-//    in registers from the enclosed / enclosing cell exactly as in sf_pf_fast.hip.h.
+//  * a thread slot owns a centre s = i+j (cell (s-j, j) of column j), so the generic interior-loop sums are
+//    carried in registers from the enclosed / enclosing cell exactly as in sf_pf_fast.hip.h.  Centres s and
+//    s+128 are never live in the same column (a column has at most W-4 <= 128 cells), so 128 slots cover all
+//    of them and every wave has work in every column.
+//  * one workgroup = 4 teams of 128 threads working on the SAME cells, split by role (wave-uniform):
+//      team 0  generic interior-loop sums (the register recurrence), small special loops, hairpin / exterior
+//      team 1  bulges                      team 2  1xn loops, then the cell's final sum and all table writes
+//      team 3  multiloop sums (inside: closing term of column j and qm of column j-1; outside: stem term of
+//              column l and R1 of column l-1)
+//    partial sums meet in LDS; two barriers per column.
 //  * qb/ob are stored column-major (a column's rows are consecutive: the lanes of a wave read consecutive
 //    doubles for every interior-loop candidate), qm diagonal-major (multiloop sums run over the offset from the
 //    thread's own row).  Interior-loop candidates come in two families:
@@ -20,14 +28,15 @@
 //         rolling buffers that hold qb (ob) pre-multiplied by the pair's own mismatch / terminal weights;
 //      A: the row is fixed per thread, the column runs with the loop size — qb (ob) times a weight taken
 //         from a 25x25 table indexed by (nucleotides at the column: wave-uniform row) x (nucleotides at the
-//         thread's row: 25 consecutive doubles, so the gather is bank-conflict free).
-// One barrier per column in either pass.  FP64 throughout; sums are re-associated with respect to the oracle
-// (agreement ~1e-12 relative).
+//         thread's row: 25 consecutive doubles, so the gather is bank-conflict free).  Column offsets and
+//         weight rows are wave-uniform and come from per-column lane tables (v_readlane).
+// FP64 throughout; sums are re-associated with respect to the oracle (agreement ~1e-12 relative).
 #pragma once
 #include "sf_energy.h"
 #include "sf_pf.hip.h"
 
-#define SF_PFL_NT 256
+#define SF_PFL_NT 512
+#define SF_PFL_SLOTS 128
 #define SF_PFL_PAD 32
 #define SF_PFL_LDS_LIMIT (160 * 1024)
 // A per-column table of wave-uniform values, one entry per lane, read back with v_readlane (no LDS round trip
@@ -48,10 +57,12 @@
 
 __host__ __device__ inline size_t sf_pfl_lds_bytes(int W) {
   const size_t NC = (size_t)(W - 4) * (W - 3) / 2, RP = W + 2 * SF_PFL_PAD, VW = W + 8;
-  const size_t dbl = 2 * NC + 12 * RP + 3 * 625 + 8 * VW + 8 + (W + 2) + (W + 3) + 8;
-  return dbl * sizeof(double) + 2 * (size_t)(W + 2) * sizeof(int) + (size_t)(W + 8);
+  const size_t dbl = 2 * NC + 12 * RP + 3 * 625 + 2 * VW + 8 + 6 * VW + 4 * VW + (W + 2) + (W + 3) + 16 + 4 * 32 + (W + 8);
+  return dbl * sizeof(double) + 2 * (size_t)(W + 2) * sizeof(int) + (size_t)(W + 8) + 64;
 }
-static inline bool sf_pfl_supported(int W) { return W >= 16 && 2 * W - 4 < SF_PFL_NT && sf_pfl_lds_bytes(W) <= SF_PFL_LDS_LIMIT; }
+static inline bool sf_pfl_supported(int W) {
+  return W >= 16 && 2 * W - 4 < 2 * SF_PFL_SLOTS && sf_pfl_lds_bytes(W) <= SF_PFL_LDS_LIMIT;
+}
 
 template <int WT>
 __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__restrict__ seqs, int n, int row_stride,
@@ -64,6 +75,8 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
   SF_DYN_SMEM(smem);
   const int W = WT ? WT : Wrt;
   const int tid = threadIdx.x;
+  const int c = tid & (SF_PFL_SLOTS - 1);            // centre slot: centres c and c + 128
+  const int team = SF_WAVE_UNIFORM(tid >> 7);        // role, the same for all lanes of a wave
   const int W1 = W + 1;
   const int NC = ((W - 4) * (W - 3)) >> 1, RP = W + 2 * SF_PFL_PAD, VW = W + 8;
   double *QB = (double *)smem;    // qb, then ob: column-major, column j holds rows 1..j-4
@@ -71,23 +84,38 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
   double *DER = QM + NC;          // [3 kinds][4 column slots][RP rows, row r at r + PAD]
   double *FAC = DER + 12 * RP;    // [3][25][25] family-A weights
   double *QM1 = FAC + 3 * 625;    // [2][VW]
-  double *RV = QM1 + 2 * VW + 8;  // R0[2], R1[2], R01[2], each VW, row r at r + 8
-  double *q5 = RV + 6 * VW + 0;       // [W+2] (the 8 pad rows of RV are taken from the tail of its last vector)
+  double *RV = QM1 + 2 * VW + 8;  // R0[2], R1[2], R01[2], each VW, row r at r + 8 (rows <= 0 stay 0)
+  double *ZP = RV + 6 * VW;       // [4 teams][VW] partial sums of the current column
+  double *q5 = ZP + 4 * VW;       // [W+2]
   double *q3 = q5 + (W + 2);      // [W+3]
-  double *red = q3 + (W + 3);     // [8]
-  int *FWD = (int *)(red + 8);    // [W+2]  S[x]*5 + S[x+1]
-  int *BWD = FWD + (W + 2);       // [W+2]  S[x]*5 + S[x-1]
-  uint8_t *S = (uint8_t *)(BWD + (W + 2));
+  double *red = q3 + (W + 3);     // [16]
+  double *WN = red + 16;          // ninio[32]
+  double *WB = WN + 32;           // bulge[32]
+  double *WIL = WB + 32;          // internal_loop[32]
+  double *WIL1N = WIL + 32;       // internal_loop[u] * ninio[u-2]
+  double *MLB = WIL1N + 32;       // MLbase^a, [W+8]
+  int *FWD = (int *)(MLB + (W + 8));  // [W+2]  packed code of (S[x], S[x+1])
+  int *BWD = FWD + (W + 2);           // [W+2]  packed code of (S[x], S[x-1])
+  uint8_t *S = (uint8_t *)(BWD + (W + 2));  // [W+8]
+  uint8_t *PT8 = S + (W + 8);               // [64] pair type of two nucleotide codes
 #define COFF(j) ((((j)-5) * ((j)-4)) >> 1)
 #define DOFF(d) (((d)-4) * W - ((((d) * ((d)-1)) >> 1) - 6))
 #define QBC(i, j) QB[COFF(j) + (i)-1]
 #define QMD(d, i) QM[DOFF(d) + (i)-1]
 #define DERP(kind, col) (DER + ((kind)*4 + ((col)&3)) * RP + SF_PFL_PAD)
-  const double *mlb = X->mlbase_pow;
+#define PAIR(a, b) PT8[(a)*8 + (b)]
   const double xTAU = X->TermAU;
   const double xMLbase = X->MLbase;
   // speculative (discarded or zero-weighted) reads below may land anywhere in the tables: keep them finite
   for (int x = tid; x < 2 * NC; x += SF_PFL_NT) QB[x] = 0.0;
+  if (tid < 32) {
+    WN[tid] = tid <= SFD_MAXLOOP ? X->ninio[tid] : 0.0;
+    WB[tid] = tid <= SFD_MAXLOOP ? X->bulge[tid] : 0.0;
+    WIL[tid] = tid <= SFD_MAXLOOP ? X->internal_loop[tid] : 0.0;
+    WIL1N[tid] = (tid >= 2 && tid <= SFD_MAXLOOP) ? X->internal_loop[tid] * X->ninio[tid - 2] : 0.0;
+  }
+  for (int x = tid; x < W + 8; x += SF_PFL_NT) MLB[x] = X->mlbase_pow[x];
+  if (tid < 64) PT8[tid] = (uint8_t)D->pair[tid >> 3][tid & 7];
 
   for (int fold = blockIdx.x; fold < n; fold += gridDim.x) {
     const uint8_t *src = seqs + (size_t)fold * row_stride * W;
@@ -95,7 +123,7 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
     for (int x = tid; x < W; x += SF_PFL_NT) S[x + 1] = sf_encode_nt(src[x]);
     if (tid == 0) { S[0] = 0; S[W + 1] = 0; }
     for (int x = tid; x < 12 * RP; x += SF_PFL_NT) DER[x] = 0.0;
-    for (int x = tid; x < 8 * VW + 8; x += SF_PFL_NT) QM1[x] = 0.0;  // QM1 and the six R vectors are contiguous
+    for (int x = tid; x < 12 * VW + 8; x += SF_PFL_NT) QM1[x] = 0.0;  // QM1, the six R vectors, the partial sums
     __syncthreads();
     for (int x = tid; x <= W + 1; x += SF_PFL_NT) {
       const int cf = S[x] * 5 + (x <= W ? S[x + 1] : 0), cb = S[x] * 5 + (x >= 1 ? S[x - 1] : 0);
@@ -117,144 +145,173 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
     double H[27];
 #pragma unroll
     for (int u = 0; u < 27; u++) H[u] = 0.0;
-    for (int j = SFD_TURN + 2; j <= W; j++) {
-      const int i = tid - j, d = j - i;
-      const bool valid = (i >= 1) && (d >= SFD_TURN + 1);
+    for (int j = SFD_TURN + 2; j <= W + 1; j++) {
+      // j = W+1 only finishes qm of column W (team 3)
+      const int s = (j <= c - 1) ? c : c + SF_PFL_SLOTS;
+      const int i = s - j, d = j - i;
+      const bool valid = (i >= 1) && (d >= SFD_TURN + 1) && (j <= W);
       double *qm1c = QM1 + (j & 1) * VW, *qm1p = QM1 + ((j & 1) ^ 1) * VW;
-      SF_LANE_TABLE(tq, L, FWD[sfd_max(j - L, 5)]);  // entry L: column j-L
-      if (valid) {
-        const int umax = sfd_min(SFD_MAXLOOP, d - 2 - (SFD_TURN + 1));
-        const int type = D->pair[S[i]][S[j]];
-        const int si1 = S[i + 1], sj1 = S[j - 1];
-        const double *dI3 = DERP(0, j - 3), *d1N2 = DERP(1, j - 2), *dB1 = DERP(2, j - 1);
-        const double *fI = FAC + SF_PK_CODE(BWD[i + 3]), *f1N = FAC + 625 + SF_PK_CODE(BWD[i + 2]);
-        // generic interior sums of this cell from those of the enclosed cell (same thread, previous column)
-        // Straight-line: family-A values are loaded speculatively (column clamped to an existing one) and
-        // dropped by a select when the inner span would be < TURN+1; family-B values are 0 there by themselves.
-        // Sizes beyond umax therefore stay exactly 0 and need no separate bookkeeping.
+      // lane tables, entry L: column max(j-L, 5)
+      SF_LANE_TABLE(tpk, L, FWD[sfd_min(sfd_max(j - L, 5), W)]);
+      SF_LANE_TABLE(tcol, L, COFF(sfd_min(sfd_max(j - L, 5), W)));
+      const int umax = sfd_min(SFD_MAXLOOP, d - 2 - (SFD_TURN + 1));
+      if (team == 0) {
+        if (valid) {
+          const int type = PAIR(S[i], S[j]);
+          const int si1 = S[i + 1], sj1 = S[j - 1];
+          if (d < SFD_TURN + 3) {  // first cell of this centre
 #pragma unroll
-        for (int u = 30; u >= 6; --u) {
-          const int q = sfd_max(j - u + 1, 5);
-          const double a = QBC(i + 3, q) * fI[SF_PK_ROW(SF_LANE_GET(tq, u - 1))];
-          H[u - 4] = H[u - 6] + ((u <= umax ? a : 0.0) + dI3[i + u - 1]) * X->ninio[u - 4];
-        }
-        {
-          const int q = sfd_max(j - 4, 5);
-          const double a = QBC(i + 3, q) * fI[SF_PK_ROW(SF_LANE_GET(tq, 4))];
-          H[1] = ((umax >= 5 ? a : 0.0) + dI3[i + 4]) * X->ninio[1];
-          H[0] = dI3[i + 3] * X->ninio[0];
-        }
-        double qbij = 0.0;
-        if (type) {
-          double z = sfx_hairpin(D, X, S, i, j, type);
-          if (umax >= 0) {
-            const double tau_out = type > 2 ? xTAU : 1.0;
-            z += QBC(i + 1, j - 1) * X->stack[type][sfd_rtype(D->pair[si1][sj1])];
-            if (umax >= 1) {
-              const int ta = sfd_rtype(D->pair[si1][S[j - 2]]), tb = sfd_rtype(D->pair[S[i + 2]][sj1]);
-              z += (QBC(i + 1, j - 2) * X->stack[type][ta] + QBC(i + 2, j - 1) * X->stack[type][tb]) * X->bulge[1];
-            }
-            if (umax >= 2) {
-              const int t2r = sfd_rtype(D->pair[S[i + 2]][S[j - 2]]);
-              z += QBC(i + 2, j - 2) * X->int11[type][t2r][si1][sj1];
-            }
-            if (umax >= 3) {
-              const int ta = sfd_rtype(D->pair[S[i + 2]][S[j - 3]]), tb = sfd_rtype(D->pair[S[i + 3]][S[j - 2]]);
-              z += QBC(i + 2, j - 3) * X->int21[type][ta][si1][S[j - 2]][sj1] +
-                   QBC(i + 3, j - 2) * X->int21[tb][type][sj1][si1][S[i + 2]];
-            }
-            if (umax >= 4) {
-              const int t2r = sfd_rtype(D->pair[S[i + 3]][S[j - 3]]);
-              z += QBC(i + 3, j - 3) * X->int22[type][t2r][si1][S[i + 2]][S[j - 2]][sj1];
-            }
-            if (umax >= 5) {
-              const int ta = sfd_rtype(D->pair[S[i + 3]][S[j - 4]]), tb = sfd_rtype(D->pair[S[i + 4]][S[j - 3]]);
-              const double m23 = X->internal_loop[5] * X->ninio[1] * X->mismatch23I[type][si1][sj1];
-              z += m23 * (QBC(i + 3, j - 4) * X->mismatch23I[ta][S[j - 3]][S[i + 2]] +
-                          QBC(i + 4, j - 3) * X->mismatch23I[tb][S[j - 2]][S[i + 3]]);
-            }
-            double gb = 0.0, g1 = 0.0, gg = 0.0;
-            const int sp = S[i + 1];  // row of the u1 = 0 bulge candidates
-#pragma unroll
-            for (int u = 2; u <= 30; ++u) {
-              const int qb_ = sfd_max(j - 1 - u, 5);
-              const double ta_ = (sp * SF_PK_NT(SF_LANE_GET(tq, u + 1)) == 6) ? 1.0 : xTAU;  // C-G / G-C: no terminal penalty
-              const double ab = QBC(i + 1, qb_) * ta_;
-              gb += ((u <= umax ? ab : 0.0) + dB1[i + 1 + u]) * X->bulge[u];
-              if (u >= 4) {
-                const int qn = sfd_max(j - u, 5);
-                const double an = QBC(i + 2, qn) * f1N[SF_PK_ROW(SF_LANE_GET(tq, u))];
-                g1 += ((u <= umax ? an : 0.0) + d1N2[i + u]) * (X->internal_loop[u] * X->ninio[u - 2]);
-              }
-              if (u >= 6) gg += H[u - 4] * X->internal_loop[u];
-            }
-            z += gb * tau_out + g1 * X->mismatch1nI[type][si1][sj1] + gg * X->mismatchI[type][si1][sj1];
+            for (int u = 0; u < 27; u++) H[u] = 0.0;
           }
-          double ml = 0.0;
+          const double *dI3 = DERP(0, j - 3) + i;
+          const double *fI = FAC + SF_PK_CODE(BWD[i + 3]);
+          const double *qbA = QB + i + 2;  // row i+3
+          // Straight-line: family-A values are loaded speculatively (column clamped to an existing one) and
+          // dropped by a select when the inner span would be < TURN+1; family-B values are 0 there by
+          // themselves.  Sizes beyond umax therefore stay exactly 0 and need no separate bookkeeping.
+#pragma unroll
+          for (int u = 30; u >= 6; --u) {
+            const double a = qbA[SF_LANE_GET(tcol, u - 1)] * fI[SF_PK_ROW(SF_LANE_GET(tpk, u - 1))];
+            H[u - 4] = H[u - 6] + ((u <= umax ? a : 0.0) + dI3[u - 1]) * WN[u - 4];
+          }
           {
-            // sum_a qm[i+1,i+a-1] qm1[i+a,j-1], a = 6..d-5; eight terms per trip, the overshoot reads rows of
-            // qm1 that are still 0 (rows > j-5 of column j-1)
-            double ml1 = 0.0;
-            const double *qmr = QM + i, *q1 = qm1p + i;
-            int off = 0, st = W - 4;  // DOFF(a-2) and its increment, a = 6
-            for (int a = SFD_TURN + 3; a <= d - SFD_TURN - 2; a += 8) {
-              double t0 = 0.0, t1 = 0.0;
-#pragma unroll
-              for (int t = 0; t < 8; t += 2) {
-                t0 += qmr[off] * q1[a + t];
-                off += st--;
-                t1 += qmr[off] * q1[a + t + 1];
-                off += st--;
-              }
-              ml += t0;
-              ml1 += t1;
-            }
-            ml += ml1;
+            const double a = qbA[SF_LANE_GET(tcol, 4)] * fI[SF_PK_ROW(SF_LANE_GET(tpk, 4))];
+            H[1] = ((umax >= 5 ? a : 0.0) + dI3[4]) * WN[1];
+            H[0] = dI3[3] * WN[0];
           }
-          z += ml * X->MLclosing * sfx_mlstem(X, sfd_rtype(type), sj1, si1);
-          qbij = z;
+          double z = 0.0;
+          if (type) {
+            z = sfx_hairpin(D, X, S, i, j, type);
+            if (umax >= 0) {
+              z += QBC(i + 1, j - 1) * X->stack[type][sfd_rtype(PAIR(si1, sj1))];
+              if (umax >= 1) {
+                const int ta = sfd_rtype(PAIR(si1, S[j - 2])), tb = sfd_rtype(PAIR(S[i + 2], sj1));
+                z += (QBC(i + 1, j - 2) * X->stack[type][ta] + QBC(i + 2, j - 1) * X->stack[type][tb]) * WB[1];
+              }
+              if (umax >= 2) {
+                const int t2r = sfd_rtype(PAIR(S[i + 2], S[j - 2]));
+                z += QBC(i + 2, j - 2) * X->int11[type][t2r][si1][sj1];
+              }
+              if (umax >= 3) {
+                const int ta = sfd_rtype(PAIR(S[i + 2], S[j - 3])), tb = sfd_rtype(PAIR(S[i + 3], S[j - 2]));
+                z += QBC(i + 2, j - 3) * X->int21[type][ta][si1][S[j - 2]][sj1] +
+                     QBC(i + 3, j - 2) * X->int21[tb][type][sj1][si1][S[i + 2]];
+              }
+              if (umax >= 4) {
+                const int t2r = sfd_rtype(PAIR(S[i + 3], S[j - 3]));
+                z += QBC(i + 3, j - 3) * X->int22[type][t2r][si1][S[i + 2]][S[j - 2]][sj1];
+              }
+              if (umax >= 5) {
+                const int ta = sfd_rtype(PAIR(S[i + 3], S[j - 4])), tb = sfd_rtype(PAIR(S[i + 4], S[j - 3]));
+                const double m23 = WIL[5] * WN[1] * X->mismatch23I[type][si1][sj1];
+                z += m23 * (QBC(i + 3, j - 4) * X->mismatch23I[ta][S[j - 3]][S[i + 2]] +
+                            QBC(i + 4, j - 3) * X->mismatch23I[tb][S[j - 2]][S[i + 3]]);
+              }
+              double gg = 0.0, gg2 = 0.0;
+#pragma unroll
+              for (int u = 6; u <= 30; u += 2) {
+                gg += H[u - 4] * WIL[u];
+                if (u + 1 <= 30) gg2 += H[u - 3] * WIL[u + 1];
+              }
+              z += (gg + gg2) * X->mismatchI[type][si1][sj1];
+            }
+          }
+          ZP[i] = z;
         }
-        {
-          const int tr = sfd_rtype(type);
-          const int sp1 = S[i - 1], sq1 = S[j + 1];
-          QBC(i, j) = qbij;
-          DERP(0, j)[i] = type ? qbij * X->mismatchI[tr][sq1][sp1] : 0.0;
-          DERP(1, j)[i] = type ? qbij * X->mismatch1nI[tr][sq1][sp1] : 0.0;
-          DERP(2, j)[i] = (type && tr > 2) ? qbij * xTAU : qbij;
-          double m1 = qm1p[i] * xMLbase;
-          if (type) m1 += qbij * sfx_mlstem(X, type, i > 1 ? sp1 : -1, j < W ? sq1 : -1);
-          qm1c[i] = m1;
+      } else if (team == 1) {
+        if (valid) {
+          const int type = PAIR(S[i], S[j]);
+          const int sp = S[i + 1];  // row of the u1 = 0 bulge candidates
+          const double *dB1 = DERP(2, j - 1) + i + 1;
+          const double *qbA = QB + i;  // row i+1
+          double gb = 0.0, gb2 = 0.0;
+#pragma unroll
+          for (int u = 2; u <= 30; ++u) {
+            const double ta_ = (sp * SF_PK_NT(SF_LANE_GET(tpk, u + 1)) == 6) ? 1.0 : xTAU;  // C-G / G-C: no terminal penalty
+            const double ab = qbA[SF_LANE_GET(tcol, u + 1)] * ta_;
+            const double t = ((u <= umax ? ab : 0.0) + dB1[u]) * WB[u];
+            if (u & 1) gb2 += t; else gb += t;
+          }
+          ZP[VW + i] = (gb + gb2) * (type > 2 ? xTAU : 1.0);
         }
-      }
-      __syncthreads();
-      if (valid) {
-        // qm[i,j] = sum_{a>=0} MLbase^a qm1[i+a,j] + sum_{a>=5} qm[i,i+a-1] qm1[i+a,j]
-        double m = qm1c[i];
-        const int amax = d - SFD_TURN - 1;
-        for (int a = 1; a <= sfd_min(amax, 4); a++) m += mlb[a] * qm1c[i + a];
-        {
-          // eight terms per trip; the overshoot reads rows > j-4 of qm1 (column j), which are 0
-          double m2 = 0.0;
-          const double *qmr = QM + i - 1, *q1 = qm1c + i;
-          int off = 0, st = W - 4;  // DOFF(a-1) and its increment, a = 5
-          for (int a = 5; a <= amax; a += 8) {
+      } else if (team == 2) {
+        if (valid) {
+          const int type = PAIR(S[i], S[j]);
+          const int si1 = S[i + 1], sj1 = S[j - 1];
+          const double *d1N2 = DERP(1, j - 2) + i;
+          const double *f1N = FAC + 625 + SF_PK_CODE(BWD[i + 2]);
+          const double *qbA = QB + i + 1;  // row i+2
+          double g1 = 0.0, g2 = 0.0;
+#pragma unroll
+          for (int u = 4; u <= 30; ++u) {
+            const double an = qbA[SF_LANE_GET(tcol, u)] * f1N[SF_PK_ROW(SF_LANE_GET(tpk, u))];
+            const double t = ((u <= umax ? an : 0.0) + d1N2[u]) * WIL1N[u];
+            if (u & 1) g2 += t; else g1 += t;
+          }
+          ZP[2 * VW + i] = (g1 + g2) * X->mismatch1nI[type][si1][sj1];
+        }
+      } else {
+        if (valid) {
+          const int type = PAIR(S[i], S[j]);
+          const int si1 = S[i + 1], sj1 = S[j - 1];
+          // sum_a qm[i+1,i+a-1] qm1[i+a,j-1], a = 6..d-5; eight terms per trip, the overshoot reads rows of
+          // qm1 that are still 0 (rows > j-5 of column j-1)
+          double ml = 0.0, ml1 = 0.0;
+          const double *qmr = QM + i, *q1 = qm1p + i;
+          int off = 0, st = W - 4;  // DOFF(a-2) and its increment, a = 6
+          for (int a = SFD_TURN + 3; a <= d - SFD_TURN - 2; a += 8) {
             double t0 = 0.0, t1 = 0.0;
 #pragma unroll
             for (int t = 0; t < 8; t += 2) {
-              t0 += (mlb[a + t] + qmr[off]) * q1[a + t];
+              t0 += qmr[off] * q1[a + t];
               off += st--;
-              t1 += (mlb[a + t + 1] + qmr[off]) * q1[a + t + 1];
+              t1 += qmr[off] * q1[a + t + 1];
+              off += st--;
+            }
+            ml += t0;
+            ml1 += t1;
+          }
+          ZP[3 * VW + i] = (ml + ml1) * X->MLclosing * sfx_mlstem(X, sfd_rtype(type), sj1, si1);
+        }
+        // qm of column j-1, row i: qm[i,j-1] = sum_{a>=0} MLbase^a qm1[i+a,j-1] + sum_{a>=5} qm[i,i+a-1] qm1[i+a,j-1]
+        const int dq = j - 1 - i;
+        if (i >= 1 && dq >= SFD_TURN + 1) {
+          double m = qm1p[i], m2 = 0.0;
+          const int amax = dq - SFD_TURN - 1;
+          for (int a = 1; a <= sfd_min(amax, 4); a++) m += MLB[a] * qm1p[i + a];
+          const double *qmr = QM + i - 1, *q1 = qm1p + i;
+          int off = 0, st = W - 4;  // DOFF(a-1) and its increment, a = 5
+          for (int a = 5; a <= amax; a += 8) {  // the overshoot reads rows > j-5 of qm1 (column j-1), which are 0
+            double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+            for (int t = 0; t < 8; t += 2) {
+              t0 += (MLB[a + t] + qmr[off]) * q1[a + t];
+              off += st--;
+              t1 += (MLB[a + t + 1] + qmr[off]) * q1[a + t + 1];
               off += st--;
             }
             m += t0;
             m2 += t1;
           }
-          m += m2;
+          QMD(dq, i) = m + m2;
         }
-        QMD(d, i) = m;
       }
+      __syncthreads();
+      if (team == 2 && valid) {
+        const int type = PAIR(S[i], S[j]);
+        const int tr = sfd_rtype(type);
+        const int sp1 = S[i - 1], sq1 = S[j + 1];
+        const double qbij = type ? (ZP[i] + ZP[VW + i]) + (ZP[2 * VW + i] + ZP[3 * VW + i]) : 0.0;
+        QBC(i, j) = qbij;
+        DERP(0, j)[i] = type ? qbij * X->mismatchI[tr][sq1][sp1] : 0.0;
+        DERP(1, j)[i] = type ? qbij * X->mismatch1nI[tr][sq1][sp1] : 0.0;
+        DERP(2, j)[i] = (type && tr > 2) ? qbij * xTAU : qbij;
+        double m1 = qm1p[i] * xMLbase;
+        if (type) m1 += qbij * sfx_mlstem(X, type, i > 1 ? sp1 : -1, j < W ? sq1 : -1);
+        qm1c[i] = m1;
+      }
+      __syncthreads();
     }
-    __syncthreads();
 
     // ================= exterior =================
     if (tid == 0) { q5[0] = 1.0; q3[W + 1] = 1.0; }
@@ -263,7 +320,7 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
       double val = 0.0;
       const int i = tid + 1;
       if (i + SFD_TURN + 1 <= j) {
-        const int type = D->pair[S[i]][S[j]];
+        const int type = PAIR(S[i], S[j]);
         if (type) val = q5[i - 1] * QBC(i, j) * sfx_extloop(X, type, i > 1 ? S[i - 1] : -1, j < W ? S[j + 1] : -1);
       }
       val = sf_block_sum(val, red);
@@ -274,7 +331,7 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
       double val = 0.0;
       const int j = tid + 1;
       if (j <= W && i + SFD_TURN + 1 <= j) {
-        const int type = D->pair[S[i]][S[j]];
+        const int type = PAIR(S[i], S[j]);
         if (type) val = QBC(i, j) * sfx_extloop(X, type, i > 1 ? S[i - 1] : -1, j < W ? S[j + 1] : -1) * q3[j + 1];
       }
       val = sf_block_sum(val, red);
@@ -301,157 +358,191 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
     for (int u = 0; u < 27; u++) H[u] = 0.0;
     double mbd = 0.0, cd = 0.0;
     for (int l = W; l >= SFD_TURN + 2; l--) {
-      const int k = tid - l, d = l - k;
+      const int s = (l <= c - 1) ? c : c + SF_PFL_SLOTS;
+      const int k = s - l, d = l - k;
       const bool valid = (k >= 1) && (d >= SFD_TURN + 1);
+      const bool inner = (k > 1) && (l < W);
       const double *R1c = RV + (2 + (l & 1)) * VW, *R01c = RV + (4 + (l & 1)) * VW, *R0c = RV + (l & 1) * VW;
       double *R0n = RV + ((l & 1) ^ 1) * VW, *R1n = RV + (2 + ((l & 1) ^ 1)) * VW, *R01n = RV + (4 + ((l & 1) ^ 1)) * VW;
-      SF_LANE_TABLE(tl, L, BWD[sfd_min(l + L, W)]);  // entry L: column l+L
-      if (valid) {
-        const bool inner = (k > 1) && (l < W);
-        const double *dI3 = DERP(0, l + 3), *d1N2 = DERP(1, l + 2), *dB1 = DERP(2, l + 1);
-        const bool c3 = l + 3 <= W, c2 = l + 2 <= W;  // the column exists (its slot holds outside values)
-        const bool r3 = k - 3 >= 1, r2 = k - 2 >= 1;   // the row exists
-        const int kr3 = r3 ? k - 3 : 1, kr2 = r2 ? k - 2 : 1;  // rows for speculative reads
-        const double *fI = FAC + SF_PK_CODE(FWD[kr3]), *f1N = FAC + 625 + SF_PK_CODE(FWD[kr2]);
-        if (!inner) {
+      // lane tables, entry L: column min(l+L, W)
+      SF_LANE_TABLE(tpk, L, BWD[sfd_min(l + L, W)]);
+      SF_LANE_TABLE(tcol, L, COFF(sfd_min(l + L, W)));
+      const bool r3 = k - 3 >= 1, r2 = k - 2 >= 1;  // the row exists
+      if (team == 0) {
+        if (valid) {
+          const double *dI3 = DERP(0, l + 3) + k;
+          const bool c3 = l + 3 <= W;  // the column exists (its slot holds outside values)
+          const int kr3 = r3 ? k - 3 : 1;  // row for speculative reads
+          const double *fI = FAC + SF_PK_CODE(FWD[kr3]);
+          const double *qbA = QB + kr3 - 1;
+          if (!inner) {
 #pragma unroll
-          for (int u = 0; u < 27; u++) H[u] = 0.0;
-        } else {
+            for (int u = 0; u < 27; u++) H[u] = 0.0;
+          } else {
 #pragma unroll
-          for (int u = 30; u >= 6; --u) {
-            const int lp = sfd_min(l + u - 1, W);
-            const double a = QBC(kr3, lp) * fI[SF_PK_ROW(SF_LANE_GET(tl, u - 1))];
-            const double e1 = (r3 && l + u - 1 <= W) ? a : 0.0;  // u1 = 2
-            const double e2 = c3 ? dI3[k - u + 1] : 0.0;         // u2 = 2
-            H[u - 4] = H[u - 6] + (e1 + e2) * X->ninio[u - 4];
+            for (int u = 30; u >= 6; --u) {
+              const double a = qbA[SF_LANE_GET(tcol, u - 1)] * fI[SF_PK_ROW(SF_LANE_GET(tpk, u - 1))];
+              const double e1 = (r3 && l + u - 1 <= W) ? a : 0.0;  // u1 = 2
+              const double e2 = c3 ? dI3[1 - u] : 0.0;             // u2 = 2
+              H[u - 4] = H[u - 6] + (e1 + e2) * WN[u - 4];
+            }
+            {
+              const double a = qbA[SF_LANE_GET(tcol, 4)] * fI[SF_PK_ROW(SF_LANE_GET(tpk, 4))];
+              const double e1 = (r3 && l + 4 <= W) ? a : 0.0;
+              const double e2 = c3 ? dI3[-4] : 0.0;
+              H[1] = (e1 + e2) * WN[1];
+            }
+            H[0] = c3 ? dI3[-3] * WN[0] : 0.0;
           }
-          {
-            const int lp = sfd_min(l + 4, W);
-            const double a = QBC(kr3, lp) * fI[SF_PK_ROW(SF_LANE_GET(tl, 4))];
-            const double e1 = (r3 && l + 4 <= W) ? a : 0.0;
-            const double e2 = c3 ? dI3[k - 4] : 0.0;
-            H[1] = (e1 + e2) * X->ninio[1];
-          }
-          H[0] = c3 ? dI3[k - 3] * X->ninio[0] : 0.0;
-        }
-        const int type = D->pair[S[k]][S[l]];
-        const double qbkl = QBC(k, l);
-        double o = 0.0;
-        if (type && qbkl != 0.0) {
-          o = q5[k - 1] * q3[l + 1] * sfx_extloop(X, type, k > 1 ? S[k - 1] : -1, l < W ? S[l + 1] : -1);
-          if (inner) {
-            const int rt = sfd_rtype(type);
-            const int sp1 = S[k - 1], sq1 = S[l + 1];
+          const int type = PAIR(S[k], S[l]);
+          double o = 0.0;
+          if (type) {
+            o = q5[k - 1] * q3[l + 1] * sfx_extloop(X, type, k > 1 ? S[k - 1] : -1, l < W ? S[l + 1] : -1);
+            if (inner) {
+              const int rt = sfd_rtype(type);
+              const int sp1 = S[k - 1], sq1 = S[l + 1];
 #define OBV(kk, ll) (((kk) >= 1 && (ll) <= W) ? QBC((kk) >= 1 ? (kk) : 1, (ll) <= W ? (ll) : W) : 0.0)
-#define TK(kk, ll) (((kk) >= 1 && (ll) <= W) ? D->pair[S[kk]][S[ll]] : 0)
+#define TK(kk, ll) (((kk) >= 1 && (ll) <= W) ? PAIR(S[kk], S[ll]) : 0)
 #define SS(x) S[(x) < 0 ? 0 : ((x) > W + 1 ? W + 1 : (x))] /* neighbours of pairs that may not exist */
-            {
-              const int tk = TK(k - 1, l + 1);
-              o += OBV(k - 1, l + 1) * X->stack[tk][rt];
-            }
-            {
-              const int ta = TK(k - 1, l + 2), tb = TK(k - 2, l + 1);
-              o += (OBV(k - 1, l + 2) * X->stack[ta][rt] + OBV(k - 2, l + 1) * X->stack[tb][rt]) * X->bulge[1];
-            }
-            {
-              const int tk = TK(k - 2, l + 2);
-              o += OBV(k - 2, l + 2) * X->int11[tk][rt][S[k - 1]][S[l + 1]];
-            }
-            {
-              const int ta = TK(k - 2, l + 3);  // u1 = 1, u2 = 2
-              o += OBV(k - 2, l + 3) * X->int21[ta][rt][S[k - 1]][sq1][SS(l + 2)];
-              const int tb = TK(k - 3, l + 2);  // u1 = 2, u2 = 1
-              o += OBV(k - 3, l + 2) * X->int21[rt][tb][sq1][SS(k - 2)][sp1];
-            }
-            {
-              const int tk = TK(k - 3, l + 3);
-              o += OBV(k - 3, l + 3) * X->int22[tk][rt][SS(k - 2)][sp1][sq1][SS(l + 2)];
-            }
-            {
-              const double m23 = X->internal_loop[5] * X->ninio[1] * X->mismatch23I[rt][sq1][sp1];
-              const int ta = TK(k - 3, l + 4), tb = TK(k - 4, l + 3);
-              o += m23 * (OBV(k - 3, l + 4) * X->mismatch23I[ta][SS(k - 2)][SS(l + 3)] +
-                          OBV(k - 4, l + 3) * X->mismatch23I[tb][SS(k - 3)][SS(l + 2)]);
-            }
+              {
+                const int tk = TK(k - 1, l + 1);
+                o += OBV(k - 1, l + 1) * X->stack[tk][rt];
+              }
+              {
+                const int ta = TK(k - 1, l + 2), tb = TK(k - 2, l + 1);
+                o += (OBV(k - 1, l + 2) * X->stack[ta][rt] + OBV(k - 2, l + 1) * X->stack[tb][rt]) * WB[1];
+              }
+              {
+                const int tk = TK(k - 2, l + 2);
+                o += OBV(k - 2, l + 2) * X->int11[tk][rt][S[k - 1]][S[l + 1]];
+              }
+              {
+                const int ta = TK(k - 2, l + 3);  // u1 = 1, u2 = 2
+                o += OBV(k - 2, l + 3) * X->int21[ta][rt][S[k - 1]][sq1][SS(l + 2)];
+                const int tb = TK(k - 3, l + 2);  // u1 = 2, u2 = 1
+                o += OBV(k - 3, l + 2) * X->int21[rt][tb][sq1][SS(k - 2)][sp1];
+              }
+              {
+                const int tk = TK(k - 3, l + 3);
+                o += OBV(k - 3, l + 3) * X->int22[tk][rt][SS(k - 2)][sp1][sq1][SS(l + 2)];
+              }
+              {
+                const double m23 = WIL[5] * WN[1] * X->mismatch23I[rt][sq1][sp1];
+                const int ta = TK(k - 3, l + 4), tb = TK(k - 4, l + 3);
+                o += m23 * (OBV(k - 3, l + 4) * X->mismatch23I[ta][SS(k - 2)][SS(l + 3)] +
+                            OBV(k - 4, l + 3) * X->mismatch23I[tb][SS(k - 3)][SS(l + 2)]);
+              }
 #undef OBV
 #undef TK
 #undef SS
-            double gb = 0.0, g1 = 0.0, gg = 0.0;
+              double gg = 0.0, gg2 = 0.0;
 #pragma unroll
-            for (int u = 2; u <= 30; ++u) {
-              const int lb = sfd_min(l + 1 + u, W);
-              const double ab = QBC(k - 1, lb) * ((sp1 * SF_PK_NT(SF_LANE_GET(tl, u + 1)) == 6) ? 1.0 : xTAU);
-              const double b1 = (l + 1 + u <= W) ? ab : 0.0;  // u1 = 0
-              const double b2 = dB1[k - 1 - u];               // u2 = 0
-              gb += (b1 + b2) * X->bulge[u];
-              if (u >= 4) {
-                const int ln = sfd_min(l + u, W);
-                const double an = QBC(kr2, ln) * f1N[SF_PK_ROW(SF_LANE_GET(tl, u))];
-                const double n1 = (r2 && l + u <= W) ? an : 0.0;  // u1 = 1
-                const double n2 = c2 ? d1N2[k - u] : 0.0;         // u2 = 1
-                g1 += (n1 + n2) * (X->internal_loop[u] * X->ninio[u - 2]);
+              for (int u = 6; u <= 30; u += 2) {
+                gg += H[u - 4] * WIL[u];
+                if (u + 1 <= 30) gg2 += H[u - 3] * WIL[u + 1];
               }
-              if (u >= 6) gg += H[u - 4] * X->internal_loop[u];
+              o += (gg + gg2) * X->mismatchI[rt][sq1][sp1];
             }
-            o += gb * (rt > 2 ? xTAU : 1.0) + g1 * X->mismatch1nI[rt][sq1][sp1] + gg * X->mismatchI[rt][sq1][sp1];
-            // (k,l) as a stem of a multiloop closed by (i,m), i < k, m > l
-            double ms = 0.0;
-            for (int a = 1; a <= sfd_min(k - 1, 5); a++) ms += mlb[a - 1] * R1c[k - a];
-            {
-              // eight closers per trip; the overshoot reads rows <= 0 of R1 / R01, which are 0
-              double ms2 = 0.0;
-              const double *qmr = QM + k, *r1p = R1c + k, *r01p = R01c + k;
-              int off = -6, st = W - 5;  // DOFF(a-2) - a and its increment, a = 6
-              for (int a = 6; a <= k - 1; a += 8) {
-                double t0 = 0.0, t1 = 0.0;
-#pragma unroll
-                for (int t = 0; t < 8; t += 2) {
-                  t0 += mlb[a + t - 1] * r1p[-a - t] + qmr[off] * r01p[-a - t];
-                  off += st--;
-                  t1 += mlb[a + t] * r1p[-a - t - 1] + qmr[off] * r01p[-a - t - 1];
-                  off += st--;
-                }
-                ms += t0;
-                ms2 += t1;
-              }
-              ms += ms2;
-            }
-            o += ms * sfx_mlstem(X, type, sp1, sq1);
           }
+          ZP[k] = o;
         }
-        {
-          const int si1 = S[k + 1], sj1 = S[l - 1];
-          QBC(k, l) = o;
-          DERP(0, l)[k] = type ? o * X->mismatchI[type][si1][sj1] : 0.0;
-          DERP(1, l)[k] = type ? o * X->mismatch1nI[type][si1][sj1] : 0.0;
-          DERP(2, l)[k] = (type > 2) ? o * xTAU : o;
-          const double w = type ? o * X->MLclosing * sfx_mlstem(X, sfd_rtype(type), sj1, si1) : 0.0;
-          const double r0 = w + xMLbase * R0c[k];
-          // R1 of the next column l-1: closers (k, m), m >= l+5, right part qm[l, m-1]
-          double r1 = 0.0;
-          const double *fW = FAC + 1250 + SF_PK_CODE(FWD[k]);
+      } else if (team == 1) {
+        if (valid) {
+          const int type = PAIR(S[k], S[l]);
+          const int sp1 = S[k - 1];
+          const double *dB1 = DERP(2, l + 1) + k - 1;
+          const double *qbA = QB + (k > 1 ? k - 2 : 0);  // row k-1 (row 1 for speculative reads)
+          double gb = 0.0, gb2 = 0.0;
+#pragma unroll
+          for (int u = 2; u <= 30; ++u) {
+            const double ab = qbA[SF_LANE_GET(tcol, u + 1)] * ((sp1 * SF_PK_NT(SF_LANE_GET(tpk, u + 1)) == 6) ? 1.0 : xTAU);
+            const double b1 = (l + 1 + u <= W) ? ab : 0.0;  // u1 = 0
+            const double t = (b1 + dB1[-u]) * WB[u];        // u2 = 0
+            if (u & 1) gb2 += t; else gb += t;
+          }
+          ZP[VW + k] = (gb + gb2) * (type > 2 ? xTAU : 1.0);  // rtype(type) > 2 <=> type > 2
+        }
+      } else if (team == 2) {
+        if (valid) {
+          const int type = PAIR(S[k], S[l]);
+          const int rt = sfd_rtype(type);
+          const int sp1 = S[k - 1], sq1 = S[l + 1];
+          const double *d1N2 = DERP(1, l + 2) + k;
+          const bool c2 = l + 2 <= W;
+          const int kr2 = r2 ? k - 2 : 1;
+          const double *f1N = FAC + 625 + SF_PK_CODE(FWD[kr2]);
+          const double *qbA = QB + kr2 - 1;
+          double g1 = 0.0, g2 = 0.0;
+#pragma unroll
+          for (int u = 4; u <= 30; ++u) {
+            const double an = qbA[SF_LANE_GET(tcol, u)] * f1N[SF_PK_ROW(SF_LANE_GET(tpk, u))];
+            const double n1 = (r2 && l + u <= W) ? an : 0.0;  // u1 = 1
+            const double n2 = c2 ? d1N2[-u] : 0.0;            // u2 = 1
+            const double t = (n1 + n2) * WIL1N[u];
+            if (u & 1) g2 += t; else g1 += t;
+          }
+          ZP[2 * VW + k] = (g1 + g2) * X->mismatch1nI[rt][sq1][sp1];
+        }
+      } else {
+        if (valid) {
+          const int type = PAIR(S[k], S[l]);
+          const int sp1 = S[k - 1], sq1 = S[l + 1];
+          // (k,l) as a stem of a multiloop closed by (i,m), i < k, m > l
+          double ms = 0.0, ms2 = 0.0;
+          for (int a = 1; a <= sfd_min(k - 1, 5); a++) ms += MLB[a - 1] * R1c[k - a];
           {
-            double r1b = 0.0;
-            int m = l + SFD_TURN + 2;
-            for (; m + 3 <= W; m += 4) {
-              r1 += QBC(k, m) * fW[SF_PK_ROW(BWD[m])] * QMD(m - 1 - l, l) +
-                    QBC(k, m + 2) * fW[SF_PK_ROW(BWD[m + 2])] * QMD(m + 1 - l, l);
-              r1b += QBC(k, m + 1) * fW[SF_PK_ROW(BWD[m + 1])] * QMD(m - l, l) +
-                     QBC(k, m + 3) * fW[SF_PK_ROW(BWD[m + 3])] * QMD(m + 2 - l, l);
+            // eight closers per trip; the overshoot reads rows <= 0 of R1 / R01, which are 0
+            const double *qmr = QM + k, *r1p = R1c + k, *r01p = R01c + k;
+            int off = -6, st = W - 5;  // DOFF(a-2) - a and its increment, a = 6
+            for (int a = 6; a <= k - 1; a += 8) {
+              double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+              for (int t = 0; t < 8; t += 2) {
+                t0 += MLB[a + t - 1] * r1p[-a - t] + qmr[off] * r01p[-a - t];
+                off += st--;
+                t1 += MLB[a + t] * r1p[-a - t - 1] + qmr[off] * r01p[-a - t - 1];
+                off += st--;
+              }
+              ms += t0;
+              ms2 += t1;
             }
-            for (; m <= W; m++) r1 += QBC(k, m) * fW[SF_PK_ROW(BWD[m])] * QMD(m - 1 - l, l);
-            r1 += r1b;
           }
-          R0n[k] = r0;
-          R1n[k] = r1;
-          R01n[k] = r0 + r1;
-          const double p = o * qbkl / Z;
-          mbd += p * (1.0 - p);
-          if (p > 0.5) {
-            cd += 1.0 - p;
-            if (centroid) { centroid[(size_t)fold * W1 + k - 1] = '('; centroid[(size_t)fold * W1 + l - 1] = ')'; }
-          } else cd += p;
+          ZP[3 * VW + k] = (ms + ms2) * sfx_mlstem(X, type, sp1, sq1);
+          // R1 of the next column l-1: closers (k, m), m >= l+5, right part qm[l, m-1]
+          double r1 = 0.0, r1b = 0.0;
+          const double *fW = FAC + 1250 + SF_PK_CODE(FWD[k]);
+          int m = l + SFD_TURN + 2;
+          for (; m + 3 <= W; m += 4) {
+            r1 += QBC(k, m) * fW[SF_PK_ROW(BWD[m])] * QMD(m - 1 - l, l) +
+                  QBC(k, m + 2) * fW[SF_PK_ROW(BWD[m + 2])] * QMD(m + 1 - l, l);
+            r1b += QBC(k, m + 1) * fW[SF_PK_ROW(BWD[m + 1])] * QMD(m - l, l) +
+                   QBC(k, m + 3) * fW[SF_PK_ROW(BWD[m + 3])] * QMD(m + 2 - l, l);
+          }
+          for (; m <= W; m++) r1 += QBC(k, m) * fW[SF_PK_ROW(BWD[m])] * QMD(m - 1 - l, l);
+          R1n[k] = r1 + r1b;
         }
+      }
+      __syncthreads();
+      if (team == 2 && valid) {
+        const int type = PAIR(S[k], S[l]);
+        const int si1 = S[k + 1], sj1 = S[l - 1];
+        const double qbkl = QBC(k, l);
+        double o = 0.0;
+        if (type && qbkl != 0.0) o = inner ? (ZP[k] + ZP[VW + k]) + (ZP[2 * VW + k] + ZP[3 * VW + k]) : ZP[k];
+        QBC(k, l) = o;
+        DERP(0, l)[k] = type ? o * X->mismatchI[type][si1][sj1] : 0.0;
+        DERP(1, l)[k] = type ? o * X->mismatch1nI[type][si1][sj1] : 0.0;
+        DERP(2, l)[k] = (type > 2) ? o * xTAU : o;
+        const double w = type ? o * X->MLclosing * sfx_mlstem(X, sfd_rtype(type), sj1, si1) : 0.0;
+        const double r0 = w + xMLbase * R0c[k];
+        R0n[k] = r0;
+        R01n[k] = r0 + R1n[k];
+        const double p = o * qbkl / Z;
+        mbd += p * (1.0 - p);
+        if (p > 0.5) {
+          cd += 1.0 - p;
+          if (centroid) { centroid[(size_t)fold * W1 + k - 1] = '('; centroid[(size_t)fold * W1 + l - 1] = ')'; }
+        } else cd += p;
       }
       __syncthreads();
     }
@@ -469,6 +560,7 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
 #undef QBC
 #undef QMD
 #undef DERP
+#undef PAIR
 }
 
 static inline hipError_t sf_pfl_configure() {

@@ -99,8 +99,9 @@ int sf_scan_dev(const uint8_t *d_transcript, int L, int W, int step, int win_beg
                 int shuffle_kind, uint64_t seed, unsigned flags, int32_t *d_energies, char *d_structure,
                 char *d_centroid, double *d_ens_div, double *d_ens_dG, void *stream);
 
-/* Diagnostics: 0 = automatic (LDS int16 kernel with int32 fallback), 1 = always the int32 kernel.
- * Results are identical in both modes; tests use it to cross-check the two kernels. */
+/* Diagnostics: 0 = automatic (LDS int16 kernel with int32 fallback), 1 = always the int32 kernel,
+ * 2 = the packed two-cells-per-lane LDS kernel for W <= 128 (experimental, slower in round 1).
+ * Results are identical in every mode; tests use it to cross-check the kernels. */
 int sf_set_kernel_mode(int mode);
 
 /* Measurement support for bench.py: HIP-event time (ms) and launch count of the dominant kernel

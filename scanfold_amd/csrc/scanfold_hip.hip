@@ -15,6 +15,7 @@
 #include "sf_energy.h"
 #include "sf_mfe_full.hip.h"
 #include "sf_mfe_fast.hip.h"
+#include "sf_mfe_pk.hip.h"
 #include "sf_pf.hip.h"
 #include "sf_pf_fast.hip.h"
 #include "sf_pf_lds.hip.h"
@@ -46,6 +47,8 @@ struct Ctx {
   int64_t prof_launches = 0, prof_folds = 0;
   int force_full = 0;
   int fast_ok = 0;
+  int mfe_kernel = 0;  // 0: one cell per lane (sf_mfe_fast.hip.h); 1: two cells per lane, packed int16, W <= 128
+                       // (sf_mfe_pk.hip.h; measured slower in round 1 — kernel mode 2 or SCANFOLD_MFE_KERNEL=pk)
   int pf_kernel = 0;  // 0: LDS-resident kernel where it fits; 1: device-memory tables (SCANFOLD_PF_KERNEL=global)
   int pf_blocks_per_cu = 4;  // 256 VGPRs per thread: 2 waves per SIMD
 } g;
@@ -223,12 +226,18 @@ int launch_mfe(const uint8_t *d_seqs, int n, int W, int32_t *d_out, hipStream_t 
     HIPCHK(hipMemsetAsync(d_cnt, 0, sizeof(int), st));
     int grid = 0, threads = 0;
     size_t lds = 0, scratch_bytes = 0;
-    sf_fast_geometry(W, g.n_cu, n, &grid, &threads, &lds, &scratch_bytes);
+    const bool pk = sf_pk_w_supported(W) && g.mfe_kernel == 1;
+    if (pk) sf_pk_geometry(W, g.n_cu, n, &grid, &lds, &scratch_bytes);
+    else sf_fast_geometry(W, g.n_cu, n, &grid, &threads, &lds, &scratch_bytes);
     rc = ensure(g.fast_scratch, scratch_bytes);
     if (rc) return rc;
     HIPCHK(hipEventRecord(e0, st));
-    sf_fast_launch(grid, threads, lds, st, d_seqs, n, W, (const SfDevParams *)g.dP, (const SfFastParams *)g.dF,
+    if (pk)
+      sf_pk_launch(grid, W, lds, st, d_seqs, n, W, (const SfDevParams *)g.dP, (const SfFastParams *)g.dF,
                    (int16_t *)g.fast_scratch.p, d_out, d_cnt, d_list, trace_stride, d_db, (int *)g.status.p);
+    else
+      sf_fast_launch(grid, threads, lds, st, d_seqs, n, W, (const SfDevParams *)g.dP, (const SfFastParams *)g.dF,
+                     (int16_t *)g.fast_scratch.p, d_out, d_cnt, d_list, trace_stride, d_db, (int *)g.status.p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(e1, st));
     // folds that left the int16 range are redone exactly
@@ -282,6 +291,8 @@ int sf_init(int device_ordinal) {
   HIPCHK(hipMalloc((void **)&g.dF, sizeof(SfFastParams)));
   HIPCHK(sf_fast_configure());
   HIPCHK(sf_pfl_configure());
+  HIPCHK(sf_pk_configure());
+  if (const char *mk = getenv("SCANFOLD_MFE_KERNEL")) g.mfe_kernel = (strcmp(mk, "pk") == 0);
   if (const char *pk = getenv("SCANFOLD_PF_KERNEL")) g.pf_kernel = (strcmp(pk, "global") == 0);
   if (const char *pb = getenv("SCANFOLD_PF_BLOCKS_PER_CU")) g.pf_blocks_per_cu = atoi(pb) > 0 ? atoi(pb) : 4;
   const char *ff = getenv("SCANFOLD_FORCE_FULL");
@@ -510,8 +521,9 @@ int sf_scan(const uint8_t *transcript, int L, int W, int step, int win_begin, in
 
 int sf_set_kernel_mode(int mode) {
   if (!g.init) return SF_ERR_NOT_INIT;
-  if (mode != 0 && mode != 1) return SF_ERR_BAD_ARG;
-  g.force_full = mode;
+  if (mode < 0 || mode > 2) return SF_ERR_BAD_ARG;
+  g.force_full = (mode == 1);
+  g.mfe_kernel = (mode == 2);
   return SF_OK;
 }
 

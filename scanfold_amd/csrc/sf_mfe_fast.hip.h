@@ -147,6 +147,7 @@ struct SfFastCtx {
   const SfFastParams *F;
   int16_t *cg;
   int W, TAU, MLbase, MLclosing, MLintern;
+  int fml_pad;  // 1: every diagonal of the fML triangle starts at an even index (sf_mfe_pk.hip.h)
   const int16_t *uNIN, *uIL, *uL1N, *uBUL;  // size-dependent terms, LDS copies (uniform reads)
 };
 
@@ -426,7 +427,9 @@ __device__ inline int sf_fast_traceback(const SfFastCtx &X, const int32_t *f5s, 
   const uint8_t *S = X.S;
   const SfDevParams *D = X.D;
 #define TC(i, j) ((int)X.cg[SF_CGIDX(i, j)])
-#define TF(i, j) (((j) - (i) < SFD_TURN + 1) ? SF_INF16 : (int)X.fML[FBASE((j) - (i)) + (i)-1])
+// diagonals of odd length are followed by one pad entry when X.fml_pad is set
+#define SF_FPADCNT(dd) ((((dd) + (W & 1)) >> 1) - 2)
+#define TF(i, j) (((j) - (i) < SFD_TURN + 1) ? SF_INF16 : (int)X.fML[FBASE((j) - (i)) + (X.fml_pad ? SF_FPADCNT((j) - (i)) : 0) + (i)-1])
 #define TPAIR(i, j) ((int)X.tPair[S[i] * 8 + S[j]])
   for (int x = lane; x < W; x += 64) dbL[x] = '.';
   int sp = 0, bad = 0;
@@ -555,6 +558,107 @@ __device__ inline int sf_fast_traceback(const SfFastCtx &X, const int32_t *f5s, 
 // the odd ones.  c[.,.] of diagonal d+1 does not depend on diagonal d (an enclosed pair spans at most d-1, the
 // multiloop split of d+1 reads fML spans <= d-3), only fML[d+1] needs its two neighbours on d — so the pair
 // (d, d+1) is computed concurrently by the two groups, then group 1 adds the neighbour term after one barrier.
+// Exterior loop f5[j] = min(f5[j-1], min_i f5[i-1] + c[i,j] + ExtLoop(i,j)), the energy / overflow record and
+// (for native windows) the traceback: ONE wave, after the fill.  Lane l owns i = l+1, l+65, ...; f5[i-1] sits
+// in its registers, c rows stream from device memory (one batch ahead), the minimum over i is a DPP wave
+// minimum.  No workgroup barrier inside.  NQ = rows per lane (ceil(W/64)).
+template <int NQ>
+__device__ __forceinline__ void sf_fast_exterior(const SfFastCtx &X, const int W, const int lane, const int seq,
+                                                 int32_t *f5s, const int16_t *tExt, const int32_t *flag,
+                                                 int16_t *stack_area, char *dbL, int32_t *__restrict__ out,
+                                                 int *__restrict__ ovf_cnt, int *__restrict__ ovf_list,
+                                                 const int trace_stride, char *__restrict__ db_out,
+                                                 int *__restrict__ status) {
+  const uint8_t *S = X.S;
+  const uint8_t *tPair = X.tPair;
+  int f5r[NQ], si[NQ], sim1[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; q++) {
+    const int i = lane + 64 * q + 1;
+    f5r[q] = 0;
+    si[q] = i <= W ? S[i] : 0;
+    sim1[q] = i <= W ? S[i - 1] : 0;
+  }
+  int f5prev = 0;
+  if (lane == 0) f5s[0] = 0;
+  constexpr int RB = 8;  // rows of c fetched per batch: one memory round trip per RB values of j
+#ifdef SF_ABL_F5
+  for (int j0 = W; j0 <= W; j0 += RB) {
+#else
+  for (int j0 = 1; j0 <= W; j0 += RB) {
+#endif
+    int cbuf[RB][NQ];
+#pragma unroll
+    for (int k = 0; k < RB; k++)
+#pragma unroll
+      for (int q = 0; q < NQ; q++) {
+        const int i = lane + 64 * q + 1, j = j0 + k;
+        cbuf[k][q] = (j <= W && i + SFD_TURN + 1 <= j) ? (int)X.cg[SF_CGIDX(i, j)] : SF_INF16;
+      }
+    // f5[j] needs f5[i-1] only for i <= j-4, so four consecutive j are independent up to the running
+    // minimum: their candidate minima (and wave reductions) are computed side by side, then chained
+#pragma unroll
+    for (int kb = 0; kb < RB; kb += 4) {
+      int vals[4];
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) {
+        const int k = kb + kk, j = j0 + k;
+        int val = SF_FAST_BIG * 2;
+        if (j <= W) {
+          const int sj = S[j], sj1 = S[j + 1];
+#pragma unroll
+          for (int q = 0; q < NQ; q++) {
+            const int i = lane + 64 * q + 1;
+            if (i + SFD_TURN + 1 <= j) {
+              const int type = tPair[si[q] * 8 + sj];
+              if (type) {
+                int ext;
+                if (i > 1 && j < W) ext = tExt[SF_TIDX(type, sim1[q], sj1)];
+                else if (i > 1) ext = X.tD5[type * 5 + sim1[q]];
+                else if (j < W) ext = X.tD3[type * 5 + sj1];
+                else ext = 0;
+                val = sfd_min(val, f5r[q] + cbuf[k][q] + ext + (type > 2 ? X.TAU : 0));
+              }
+            }
+          }
+        }
+        vals[kk] = sf_wave_min(val);
+      }
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) {
+        const int j = j0 + kb + kk;
+        if (j <= W) {
+          const int f5j = sfd_min(f5prev, vals[kk]);
+          f5prev = f5j;
+          if (lane == 0) f5s[j] = f5j;
+#pragma unroll
+          for (int q = 0; q < NQ; q++)
+            if (lane + 64 * q == j) f5r[q] = f5j;
+        }
+      }
+    }
+  }
+  SF_WAVE_SYNC();  // f5s[] was written by lane 0, the traceback reads it from every lane
+  const int over = flag[0] || f5prev < SF_FAST_OVF;
+  if (lane == 0) {
+    out[seq] = f5prev;
+    if (over) {
+      const int k = atomicAdd(ovf_cnt, 1);
+      ovf_list[k] = seq;
+    }
+  }
+  // ---- traceback for the sequences whose structure is wanted (native windows) ----
+  if (db_out && !over && (seq % trace_stride) == 0) {
+    int16_t *stI = stack_area;
+    int16_t *stJ = stI + W + 8;
+    int16_t *stM = stJ + W + 8;
+    const int bad = sf_fast_traceback(X, f5s, tExt, lane, stI, stJ, stM, dbL);
+    char *dst = db_out + (size_t)(seq / trace_stride) * (W + 1);
+    for (int x = lane; x <= W; x += 64) dst[x] = x < W ? dbL[x] : 0;
+    if (bad && lane == 0) atomicOr(status, 1);
+  }
+}
+
 #ifdef SF_STAMP
 // diagnostic build only: per-wave cycle totals of block 0 (cell work / barrier 1 / odd finalize / barrier 2 / exterior)
 __device__ unsigned long long sf_stamp_acc[8][8];
@@ -589,7 +693,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
   int32_t *flag = (int32_t *)(smem + Lo.off_flag);
   uint8_t *S = (uint8_t *)(smem + Lo.off_S);
   X.S = S;
-  X.D = D; X.F = F; X.W = W;
+  X.D = D; X.F = F; X.W = W; X.fml_pad = 0;
   X.TAU = D->P.TerminalAU; X.MLbase = D->P.MLbase; X.MLclosing = D->P.MLclosing; X.MLintern = D->P.MLintern[1];
   // exterior pass aliases (the rolling CI area is dead by then)
   int32_t *f5s = (int32_t *)(smem + Lo.off_ci);
@@ -689,97 +793,9 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
     if (ovf) flag[0] = 1;
     for (int x = tid; x < 200; x += NT) tExt[x] = F->mmExt[x];
     __syncthreads();
-    if (tid < 64) {
-      constexpr int NQ = NG / 64;
-      const int lane = tid;
-      int f5r[NQ], si[NQ], sim1[NQ];
-#pragma unroll
-      for (int q = 0; q < NQ; q++) {
-        const int i = lane + 64 * q + 1;
-        f5r[q] = 0;
-        si[q] = i <= W ? S[i] : 0;
-        sim1[q] = i <= W ? S[i - 1] : 0;
-      }
-      int f5prev = 0;
-      if (lane == 0) f5s[0] = 0;
-      constexpr int RB = 8;  // rows of c fetched per batch: one memory round trip per RB values of j
-#ifdef SF_ABL_F5
-      for (int j0 = W; j0 <= W; j0 += RB) {
-#else
-      for (int j0 = 1; j0 <= W; j0 += RB) {
-#endif
-        int cbuf[RB][NQ];
-#pragma unroll
-        for (int k = 0; k < RB; k++)
-#pragma unroll
-          for (int q = 0; q < NQ; q++) {
-            const int i = lane + 64 * q + 1, j = j0 + k;
-            cbuf[k][q] = (j <= W && i + SFD_TURN + 1 <= j) ? (int)X.cg[SF_CGIDX(i, j)] : SF_INF16;
-          }
-        // f5[j] needs f5[i-1] only for i <= j-4, so four consecutive j are independent up to the running
-        // minimum: their candidate minima (and wave reductions) are computed side by side, then chained
-#pragma unroll
-        for (int kb = 0; kb < RB; kb += 4) {
-          int vals[4];
-#pragma unroll
-          for (int kk = 0; kk < 4; kk++) {
-            const int k = kb + kk, j = j0 + k;
-            int val = SF_FAST_BIG * 2;
-            if (j <= W) {
-              const int sj = S[j], sj1 = S[j + 1];
-#pragma unroll
-              for (int q = 0; q < NQ; q++) {
-                const int i = lane + 64 * q + 1;
-                if (i + SFD_TURN + 1 <= j) {
-                  const int type = tPair[si[q] * 8 + sj];
-                  if (type) {
-                    int ext;
-                    if (i > 1 && j < W) ext = tExt[SF_TIDX(type, sim1[q], sj1)];
-                    else if (i > 1) ext = X.tD5[type * 5 + sim1[q]];
-                    else if (j < W) ext = X.tD3[type * 5 + sj1];
-                    else ext = 0;
-                    val = sfd_min(val, f5r[q] + cbuf[k][q] + ext + (type > 2 ? X.TAU : 0));
-                  }
-                }
-              }
-            }
-            vals[kk] = sf_wave_min(val);
-          }
-#pragma unroll
-          for (int kk = 0; kk < 4; kk++) {
-            const int j = j0 + kb + kk;
-            if (j <= W) {
-              const int f5j = sfd_min(f5prev, vals[kk]);
-              f5prev = f5j;
-              if (lane == 0) f5s[j] = f5j;
-#pragma unroll
-              for (int q = 0; q < NQ; q++)
-                if (lane + 64 * q == j) f5r[q] = f5j;
-            }
-          }
-        }
-      }
-      SF_WAVE_SYNC();  // f5s[] was written by lane 0, the traceback reads it from every lane
-      const int over = flag[0] || f5prev < SF_FAST_OVF;
-      if (lane == 0) {
-        out[seq] = f5prev;
-        if (over) {
-          const int k = atomicAdd(ovf_cnt, 1);
-          ovf_list[k] = seq;
-        }
-      }
-      // ---- traceback for the sequences whose structure is wanted (native windows) ----
-      if (db_out && !over && (seq % trace_stride) == 0) {
-        int16_t *stI = (int16_t *)(smem + Lo.off_c1n);
-        int16_t *stJ = stI + W + 8;
-        int16_t *stM = stJ + W + 8;
-        char *dbL = (char *)(smem + Lo.off_cb);
-        const int bad = sf_fast_traceback(X, f5s, tExt, lane, stI, stJ, stM, dbL);
-        char *dst = db_out + (size_t)(seq / trace_stride) * (W + 1);
-        for (int x = lane; x <= W; x += 64) dst[x] = x < W ? dbL[x] : 0;
-        if (bad && lane == 0) atomicOr(status, 1);
-      }
-    }
+    if (tid < 64)
+      sf_fast_exterior<NG / 64>(X, W, tid, seq, f5s, tExt, flag, (int16_t *)(smem + Lo.off_c1n), (char *)(smem + Lo.off_cb),
+                                out, ovf_cnt, ovf_list, trace_stride, db_out, status);
 #ifdef SF_STAMP
     if (blockIdx.x == 0 && (tid & 63) == 0) sf_stamp_acc[tid >> 6][4] += SF_T() - tf0;
 #endif

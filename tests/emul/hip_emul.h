@@ -156,6 +156,8 @@ inline T atomicOr(T *p, T v) { T o = *p; *p = o | v; return o; }
 #define SF_WAVE_SYNC() sfemul::wave_barrier()
 #define SF_WAVE_UNIFORM(x) (x)
 #define SF_SCHED_GROUP(mask, n) ((void)0)
+#define SF_SCHED_FENCE() ((void)0)
+#define SF_PIN(x) ((void)0)
 
 /* dynamic shared memory */
 #define SF_DYN_SMEM(name) char *name = sfemul::g_blk->smem.data()

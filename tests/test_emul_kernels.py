@@ -32,6 +32,22 @@ def test_fast_and_full_mfe_kernels_match_oracle(emul, oracle):
         assert (emul.mfe_batch(arr) == ref).all(), W
         emul.set_kernel_mode(1)
         assert (emul.mfe_batch(arr) == ref).all(), W
+        emul.set_kernel_mode(2)  # packed two-cells-per-lane kernel (W <= 128; the emulation aborts on a misaligned pair read)
+        assert (emul.mfe_batch(arr) == ref).all(), W
+        emul.set_kernel_mode(0)
+
+
+def test_packed_kernel_odd_widths_and_traceback(emul, oracle):
+    emul.load_params(params.default_params())
+    rng = np.random.default_rng(11)
+    emul.set_kernel_mode(2)
+    try:
+        for W in (16, 61, 99, 127, 128):
+            arr = random_seqs(rng, 3, W)
+            e, db = emul.mfe_trace_batch(arr)
+            for k in range(len(arr)):
+                assert (db[k], e[k]) == oracle.mfe(bytes(arr[k]).decode()), (W, k)
+    finally:
         emul.set_kernel_mode(0)
 
 

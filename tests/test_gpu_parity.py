@@ -52,9 +52,12 @@ def test_mfe_energy_parity_both_kernels(gpu_engine, oracle, W, n):
     fast = gpu_engine.mfe_batch(arr)
     gpu_engine.set_kernel_mode(1)
     full = gpu_engine.mfe_batch(arr[: min(n, 512)])
+    gpu_engine.set_kernel_mode(2)  # packed two-cells-per-lane kernel (falls back to mode 0 above W = 128)
+    packed = gpu_engine.mfe_batch(arr)
     gpu_engine.set_kernel_mode(0)
     assert (fast == ref).all(), int((fast != ref).sum())
     assert (full == ref[: len(full)]).all()
+    assert (packed == ref).all(), int((packed != ref).sum())
 
 
 def test_biased_compositions_and_int16_overflow_fallback(gpu_engine, oracle):

@@ -1,0 +1,16 @@
+#!/bin/bash
+# per-fold PMC counters of the batched MFE kernel (rocprofv3 counter passes; run on the GPU box)
+cd /tmp && export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; rm -rf $R/gpurun_out/pkpmc
+for c in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_WAIT_INST_LDS"; do
+  d=$R/gpurun_out/pkpmc/$(echo $c | tr " " "_" | cut -c1-40)
+  timeout 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $d -- python3 $R/tools/gpu_mfe_only.py 131072 120 > /dev/null 2>&1
+done
+python3 - <<PY
+import csv, glob
+for f in sorted(glob.glob("$R/gpurun_out/pkpmc/*/*/*counter_collection.csv")):
+    acc = {}
+    for r in csv.DictReader(open(f)):
+        if "sf_mfe_" in r["Kernel_Name"] and "full" not in r["Kernel_Name"] and int(r["Grid_Size"]) >= 1024*128:
+            acc[r["Counter_Name"]] = acc.get(r["Counter_Name"], 0) + float(r["Counter_Value"])
+    print({k: "%.3g" % (v/131072) for k,v in acc.items()})
+PY

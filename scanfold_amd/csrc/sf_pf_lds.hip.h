@@ -18,8 +18,9 @@
 //  * one workgroup = 4 teams of 128 threads working on the SAME cells, split by role (wave-uniform):
 //      team 0  generic interior-loop sums (the register recurrence), small special loops, hairpin / exterior
 //      team 1  bulges                      team 2  1xn loops, then the cell's final sum and all table writes
-//      team 3  multiloop sums (inside: closing term of column j and qm of column j-1; outside: stem term of
-//              column l and R1 of column l-1)
+//      team 3  multiloop sum of the cell (inside: closing term, plus the hairpin; outside: stem term)
+//      teams 1 and 2 also share the second O(W) sum of a column (inside: qm of column j-1; outside: R1 of
+//      column l-1), half of its range each — that balances the four roles to within ~20 %
 //    partial sums meet in LDS; two barriers per column.
 //  * qb/ob are stored column-major (a column's rows are consecutive: the lanes of a wave read consecutive
 //    doubles for every interior-loop candidate), qm diagonal-major (multiloop sums run over the offset from the
@@ -57,7 +58,7 @@
 
 __host__ __device__ inline size_t sf_pfl_lds_bytes(int W) {
   const size_t NC = (size_t)(W - 4) * (W - 3) / 2, RP = W + 2 * SF_PFL_PAD, VW = W + 8;
-  const size_t dbl = 2 * NC + 12 * RP + 3 * 625 + 2 * VW + 8 + 6 * VW + 4 * VW + (W + 2) + (W + 3) + 16 + 4 * 32 + (W + 8);
+  const size_t dbl = 2 * NC + 12 * RP + 3 * 625 + 2 * VW + 8 + 6 * VW + 5 * VW + (W + 2) + (W + 3) + 16 + 4 * 32 + (W + 8);
   return dbl * sizeof(double) + 2 * (size_t)(W + 2) * sizeof(int) + (size_t)(W + 8) + 64;
 }
 static inline bool sf_pfl_supported(int W) {
@@ -85,8 +86,8 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
   double *FAC = DER + 12 * RP;    // [3][25][25] family-A weights
   double *QM1 = FAC + 3 * 625;    // [2][VW]
   double *RV = QM1 + 2 * VW + 8;  // R0[2], R1[2], R01[2], each VW, row r at r + 8 (rows <= 0 stay 0)
-  double *ZP = RV + 6 * VW;       // [4 teams][VW] partial sums of the current column
-  double *q5 = ZP + 4 * VW;       // [W+2]
+  double *ZP = RV + 6 * VW;       // [4 teams][VW] partial sums of the current column, [4] = team 1's half of qm / R1
+  double *q5 = ZP + 5 * VW;       // [W+2]
   double *q3 = q5 + (W + 2);      // [W+3]
   double *red = q3 + (W + 3);     // [16]
   double *WN = red + 16;          // ninio[32]
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
     for (int x = tid; x < W; x += SF_PFL_NT) S[x + 1] = sf_encode_nt(src[x]);
     if (tid == 0) { S[0] = 0; S[W + 1] = 0; }
     for (int x = tid; x < 12 * RP; x += SF_PFL_NT) DER[x] = 0.0;
-    for (int x = tid; x < 12 * VW + 8; x += SF_PFL_NT) QM1[x] = 0.0;  // QM1, the six R vectors, the partial sums
+    for (int x = tid; x < 13 * VW + 8; x += SF_PFL_NT) QM1[x] = 0.0;  // QM1, the six R vectors, the partial sums
     __syncthreads();
     for (int x = tid; x <= W + 1; x += SF_PFL_NT) {
       const int cf = S[x] * 5 + (x <= W ? S[x + 1] : 0), cb = S[x] * 5 + (x >= 1 ? S[x - 1] : 0);
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
 #pragma unroll
     for (int u = 0; u < 27; u++) H[u] = 0.0;
     for (int j = SFD_TURN + 2; j <= W + 1; j++) {
-      // j = W+1 only finishes qm of column W (team 3)
+      // j = W+1 only finishes qm of column W
       const int s = (j <= c - 1) ? c : c + SF_PFL_SLOTS;
       const int i = s - j, d = j - i;
       const bool valid = (i >= 1) && (d >= SFD_TURN + 1) && (j <= W);
@@ -155,6 +156,38 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
       SF_LANE_TABLE(tpk, L, FWD[sfd_min(sfd_max(j - L, 5), W)]);
       SF_LANE_TABLE(tcol, L, COFF(sfd_min(sfd_max(j - L, 5), W)));
       const int umax = sfd_min(SFD_MAXLOOP, d - 2 - (SFD_TURN + 1));
+      // qm of column j-1, row i:  qm[i,j-1] = sum_{a>=0} MLbase^a qm1[i+a,j-1] + sum_{a>=5} qm[i,i+a-1] qm1[i+a,j-1].
+      // The a >= 5 part runs in blocks of eight terms; team 1 takes the first half of the blocks (plus the
+      // a < 5 terms), team 2 the rest; the overshoot of the last block reads rows > j-5 of qm1, which are 0.
+      const int dq = j - 1 - i;
+      const bool qvalid = (i >= 1) && (dq >= SFD_TURN + 1);
+      auto qm_part = [&](const int half) -> double {
+        const int amax = dq - SFD_TURN - 1;
+        const int nb = (amax - 4 + 7) >> 3, nb1 = nb >> 1;  // blocks of eight terms starting at a = 5
+        double m = 0.0, m2 = 0.0;
+        if (half == 0) {
+          m = qm1p[i];
+          for (int a = 1; a <= sfd_min(amax, 4); a++) m += MLB[a] * qm1p[i + a];
+        }
+        const int b0 = half ? nb1 : 0, b1 = half ? nb : nb1;
+        const int a0 = 5 + 8 * b0;
+        const double *qmr = QM + i - 1, *q1 = qm1p + i;
+        int off = DOFF(a0 - 1), st = W - (a0 - 1);  // DOFF(a-1) and its increment
+        for (int a = a0; a < 5 + 8 * b1; a += 8) {
+          double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+          for (int t = 0; t < 8; t += 2) {
+            t0 += (MLB[a + t] + qmr[off]) * q1[a + t];
+            off += st--;
+            t1 += (MLB[a + t + 1] + qmr[off]) * q1[a + t + 1];
+            off += st--;
+          }
+          m += t0;
+          m2 += t1;
+        }
+        return m + m2;
+      };
+      double qm_half = 0.0;  // team 2's half of qm[i,j-1], completed after the barrier
       if (team == 0) {
         if (valid) {
           const int type = PAIR(S[i], S[j]);
@@ -179,42 +212,36 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
             H[1] = ((umax >= 5 ? a : 0.0) + dI3[4]) * WN[1];
             H[0] = dI3[3] * WN[0];
           }
-          double z = 0.0;
-          if (type) {
-            z = sfx_hairpin(D, X, S, i, j, type);
-            if (umax >= 0) {
-              z += QBC(i + 1, j - 1) * X->stack[type][sfd_rtype(PAIR(si1, sj1))];
-              if (umax >= 1) {
-                const int ta = sfd_rtype(PAIR(si1, S[j - 2])), tb = sfd_rtype(PAIR(S[i + 2], sj1));
-                z += (QBC(i + 1, j - 2) * X->stack[type][ta] + QBC(i + 2, j - 1) * X->stack[type][tb]) * WB[1];
-              }
-              if (umax >= 2) {
-                const int t2r = sfd_rtype(PAIR(S[i + 2], S[j - 2]));
-                z += QBC(i + 2, j - 2) * X->int11[type][t2r][si1][sj1];
-              }
-              if (umax >= 3) {
-                const int ta = sfd_rtype(PAIR(S[i + 2], S[j - 3])), tb = sfd_rtype(PAIR(S[i + 3], S[j - 2]));
-                z += QBC(i + 2, j - 3) * X->int21[type][ta][si1][S[j - 2]][sj1] +
-                     QBC(i + 3, j - 2) * X->int21[tb][type][sj1][si1][S[i + 2]];
-              }
-              if (umax >= 4) {
-                const int t2r = sfd_rtype(PAIR(S[i + 3], S[j - 3]));
-                z += QBC(i + 3, j - 3) * X->int22[type][t2r][si1][S[i + 2]][S[j - 2]][sj1];
-              }
-              if (umax >= 5) {
-                const int ta = sfd_rtype(PAIR(S[i + 3], S[j - 4])), tb = sfd_rtype(PAIR(S[i + 4], S[j - 3]));
-                const double m23 = WIL[5] * WN[1] * X->mismatch23I[type][si1][sj1];
-                z += m23 * (QBC(i + 3, j - 4) * X->mismatch23I[ta][S[j - 3]][S[i + 2]] +
-                            QBC(i + 4, j - 3) * X->mismatch23I[tb][S[j - 2]][S[i + 3]]);
-              }
-              double gg = 0.0, gg2 = 0.0;
+          // Small special loops, branch-free: every weight (device-memory gathers) and every inner qb is fetched
+          // unconditionally — so the fetches overlap — with columns clamped to existing ones; an inner cell
+          // that does not exist (span < TURN+1) is dropped by a select.  (The hairpin term is team 3's.)
+          const int s2 = S[i + 2], s3 = S[i + 3], s4 = S[i + 4], t2 = S[j - 2], t3 = S[j - 3], t4 = S[j - 4];
+          const int c1 = sfd_max(j - 1, 5), c2 = sfd_max(j - 2, 5), c3 = sfd_max(j - 3, 5), c4 = sfd_max(j - 4, 5);
+          const double w00 = X->stack[type][sfd_rtype(PAIR(si1, sj1))];
+          const double w01 = X->stack[type][sfd_rtype(PAIR(si1, t2))], w10 = X->stack[type][sfd_rtype(PAIR(s2, sj1))];
+          const double w11 = X->int11[type][sfd_rtype(PAIR(s2, t2))][si1][sj1];
+          const double w12 = X->int21[type][sfd_rtype(PAIR(s2, t3))][si1][t2][sj1];
+          const double w21 = X->int21[sfd_rtype(PAIR(s3, t2))][type][sj1][si1][s2];
+          const double w22 = X->int22[type][sfd_rtype(PAIR(s3, t3))][si1][s2][t2][sj1];
+          const double w23o = X->mismatch23I[type][si1][sj1];
+          const double w23 = X->mismatch23I[sfd_rtype(PAIR(s3, t4))][t3][s2], w32 = X->mismatch23I[sfd_rtype(PAIR(s4, t3))][t2][s3];
+          const double wI = X->mismatchI[type][si1][sj1];
+          const double q00 = QBC(i + 1, c1), q01 = QBC(i + 1, c2), q10 = QBC(i + 2, c1), q11 = QBC(i + 2, c2);
+          const double q12 = QBC(i + 2, c3), q21 = QBC(i + 3, c2), q22 = QBC(i + 3, c3), q23 = QBC(i + 3, c4), q32 = QBC(i + 4, c3);
+          double z = (umax >= 0 ? q00 : 0.0) * w00;
+          z += ((umax >= 1 ? q01 : 0.0) * w01 + (umax >= 1 ? q10 : 0.0) * w10) * WB[1];
+          z += (umax >= 2 ? q11 : 0.0) * w11;
+          z += (umax >= 3 ? q12 : 0.0) * w12 + (umax >= 3 ? q21 : 0.0) * w21;
+          z += (umax >= 4 ? q22 : 0.0) * w22;
+          z += (WIL[5] * WN[1] * w23o) * ((umax >= 5 ? q23 : 0.0) * w23 + (umax >= 5 ? q32 : 0.0) * w32);
+          {
+            double gg = 0.0, gg2 = 0.0;
 #pragma unroll
-              for (int u = 6; u <= 30; u += 2) {
-                gg += H[u - 4] * WIL[u];
-                if (u + 1 <= 30) gg2 += H[u - 3] * WIL[u + 1];
-              }
-              z += (gg + gg2) * X->mismatchI[type][si1][sj1];
+            for (int u = 6; u <= 30; u += 2) {
+              gg += H[u - 4] * WIL[u];
+              if (u + 1 <= 30) gg2 += H[u - 3] * WIL[u + 1];
             }
+            z += (gg + gg2) * wI;
           }
           ZP[i] = z;
         }
@@ -234,7 +261,9 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
           }
           ZP[VW + i] = (gb + gb2) * (type > 2 ? xTAU : 1.0);
         }
+        if (qvalid) ZP[4 * VW + i] = qm_part(0);
       } else if (team == 2) {
+        if (qvalid) qm_half = qm_part(1);
         if (valid) {
           const int type = PAIR(S[i], S[j]);
           const int si1 = S[i + 1], sj1 = S[j - 1];
@@ -271,32 +300,12 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
             ml += t0;
             ml1 += t1;
           }
-          ZP[3 * VW + i] = (ml + ml1) * X->MLclosing * sfx_mlstem(X, sfd_rtype(type), sj1, si1);
-        }
-        // qm of column j-1, row i: qm[i,j-1] = sum_{a>=0} MLbase^a qm1[i+a,j-1] + sum_{a>=5} qm[i,i+a-1] qm1[i+a,j-1]
-        const int dq = j - 1 - i;
-        if (i >= 1 && dq >= SFD_TURN + 1) {
-          double m = qm1p[i], m2 = 0.0;
-          const int amax = dq - SFD_TURN - 1;
-          for (int a = 1; a <= sfd_min(amax, 4); a++) m += MLB[a] * qm1p[i + a];
-          const double *qmr = QM + i - 1, *q1 = qm1p + i;
-          int off = 0, st = W - 4;  // DOFF(a-1) and its increment, a = 5
-          for (int a = 5; a <= amax; a += 8) {  // the overshoot reads rows > j-5 of qm1 (column j-1), which are 0
-            double t0 = 0.0, t1 = 0.0;
-#pragma unroll
-            for (int t = 0; t < 8; t += 2) {
-              t0 += (MLB[a + t] + qmr[off]) * q1[a + t];
-              off += st--;
-              t1 += (MLB[a + t + 1] + qmr[off]) * q1[a + t + 1];
-              off += st--;
-            }
-            m += t0;
-            m2 += t1;
-          }
-          QMD(dq, i) = m + m2;
+          ZP[3 * VW + i] = (ml + ml1) * X->MLclosing * sfx_mlstem(X, sfd_rtype(type), sj1, si1) +
+                           (type ? sfx_hairpin(D, X, S, i, j, type) : 0.0);
         }
       }
       __syncthreads();
+      if (team == 2 && qvalid) QMD(dq, i) = qm_half + ZP[4 * VW + i];
       if (team == 2 && valid) {
         const int type = PAIR(S[i], S[j]);
         const int tr = sfd_rtype(type);
@@ -368,6 +377,24 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
       SF_LANE_TABLE(tpk, L, BWD[sfd_min(l + L, W)]);
       SF_LANE_TABLE(tcol, L, COFF(sfd_min(l + L, W)));
       const bool r3 = k - 3 >= 1, r2 = k - 2 >= 1;  // the row exists
+      // R1 of the next column l-1, row k: closers (k, m), m >= l+5, right part qm[l, m-1]; the range of m is the
+      // same for every row: team 1 takes its first half, team 2 the rest
+      auto r1_part = [&](const int half) -> double {
+        double r1 = 0.0, r1b = 0.0;
+        const double *fW = FAC + 1250 + SF_PK_CODE(FWD[k]);
+        const int mlo = l + SFD_TURN + 2, mmid = mlo + ((sfd_max(W + 1 - mlo, 0) >> 1) & ~3);
+        int m = half ? mmid : mlo;
+        const int mhi = half ? W : mmid - 1;
+        for (; m + 3 <= mhi; m += 4) {
+          r1 += QBC(k, m) * fW[SF_PK_ROW(BWD[m])] * QMD(m - 1 - l, l) +
+                QBC(k, m + 2) * fW[SF_PK_ROW(BWD[m + 2])] * QMD(m + 1 - l, l);
+          r1b += QBC(k, m + 1) * fW[SF_PK_ROW(BWD[m + 1])] * QMD(m - l, l) +
+                 QBC(k, m + 3) * fW[SF_PK_ROW(BWD[m + 3])] * QMD(m + 2 - l, l);
+        }
+        for (; m <= mhi; m++) r1 += QBC(k, m) * fW[SF_PK_ROW(BWD[m])] * QMD(m - 1 - l, l);
+        return r1 + r1b;
+      };
+      double r1_half = 0.0;  // team 2's half of R1[k], completed after the barrier
       if (team == 0) {
         if (valid) {
           const double *dI3 = DERP(0, l + 3) + k;
@@ -395,55 +422,46 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
             H[0] = c3 ? dI3[-3] * WN[0] : 0.0;
           }
           const int type = PAIR(S[k], S[l]);
-          double o = 0.0;
-          if (type) {
-            o = q5[k - 1] * q3[l + 1] * sfx_extloop(X, type, k > 1 ? S[k - 1] : -1, l < W ? S[l + 1] : -1);
-            if (inner) {
-              const int rt = sfd_rtype(type);
-              const int sp1 = S[k - 1], sq1 = S[l + 1];
-#define OBV(kk, ll) (((kk) >= 1 && (ll) <= W) ? QBC((kk) >= 1 ? (kk) : 1, (ll) <= W ? (ll) : W) : 0.0)
-#define TK(kk, ll) (((kk) >= 1 && (ll) <= W) ? PAIR(S[kk], S[ll]) : 0)
-#define SS(x) S[(x) < 0 ? 0 : ((x) > W + 1 ? W + 1 : (x))] /* neighbours of pairs that may not exist */
-              {
-                const int tk = TK(k - 1, l + 1);
-                o += OBV(k - 1, l + 1) * X->stack[tk][rt];
-              }
-              {
-                const int ta = TK(k - 1, l + 2), tb = TK(k - 2, l + 1);
-                o += (OBV(k - 1, l + 2) * X->stack[ta][rt] + OBV(k - 2, l + 1) * X->stack[tb][rt]) * WB[1];
-              }
-              {
-                const int tk = TK(k - 2, l + 2);
-                o += OBV(k - 2, l + 2) * X->int11[tk][rt][S[k - 1]][S[l + 1]];
-              }
-              {
-                const int ta = TK(k - 2, l + 3);  // u1 = 1, u2 = 2
-                o += OBV(k - 2, l + 3) * X->int21[ta][rt][S[k - 1]][sq1][SS(l + 2)];
-                const int tb = TK(k - 3, l + 2);  // u1 = 2, u2 = 1
-                o += OBV(k - 3, l + 2) * X->int21[rt][tb][sq1][SS(k - 2)][sp1];
-              }
-              {
-                const int tk = TK(k - 3, l + 3);
-                o += OBV(k - 3, l + 3) * X->int22[tk][rt][SS(k - 2)][sp1][sq1][SS(l + 2)];
-              }
-              {
-                const double m23 = WIL[5] * WN[1] * X->mismatch23I[rt][sq1][sp1];
-                const int ta = TK(k - 3, l + 4), tb = TK(k - 4, l + 3);
-                o += m23 * (OBV(k - 3, l + 4) * X->mismatch23I[ta][SS(k - 2)][SS(l + 3)] +
-                            OBV(k - 4, l + 3) * X->mismatch23I[tb][SS(k - 3)][SS(l + 2)]);
-              }
-#undef OBV
-#undef TK
-#undef SS
-              double gg = 0.0, gg2 = 0.0;
+          // exterior term, then the small special loops with (k,l) as the INNER pair — branch-free as in the
+          // inside pass: rows / columns clamped to existing ones, enclosing pairs that do not exist dropped by
+          // a select, all weights fetched up front
+          const int rt = sfd_rtype(type);
+          const int sp1 = S[k - 1], sq1 = S[l + 1];
+          const int k1 = sfd_max(k - 1, 1), k2 = sfd_max(k - 2, 1), k3 = sfd_max(k - 3, 1), k4 = sfd_max(k - 4, 1);
+          const int l1 = sfd_min(l + 1, W), l2 = sfd_min(l + 2, W), l3 = sfd_min(l + 3, W), l4 = sfd_min(l + 4, W);
+          const bool e1 = inner, e2k = k - 2 >= 1, e3k = k - 3 >= 1, e4k = k - 4 >= 1;
+          const bool e2l = l + 2 <= W, e3l = l + 3 <= W, e4l = l + 4 <= W;
+          const int sk2 = S[k2], sk3 = S[k3], sl2 = S[l2], sl3 = S[l3];  // neighbours towards the loop
+          const double w00 = X->stack[PAIR(S[k1], S[l1])][rt];
+          const double w01 = X->stack[PAIR(S[k1], S[l2])][rt], w10 = X->stack[PAIR(S[k2], S[l1])][rt];
+          const double w11 = X->int11[PAIR(S[k2], S[l2])][rt][sp1][sq1];
+          const double w12 = X->int21[PAIR(S[k2], S[l3])][rt][sp1][sq1][sl2];  // u1 = 1, u2 = 2
+          const double w21 = X->int21[rt][PAIR(S[k3], S[l2])][sq1][sk2][sp1];  // u1 = 2, u2 = 1
+          const double w22 = X->int22[PAIR(S[k3], S[l3])][rt][sk2][sp1][sq1][sl2];
+          const double w23o = X->mismatch23I[rt][sq1][sp1];
+          const double w23 = X->mismatch23I[PAIR(S[k3], S[l4])][sk2][sl3], w32 = X->mismatch23I[PAIR(S[k4], S[l3])][sk3][sl2];
+          const double wI = X->mismatchI[rt][sq1][sp1];
+          const double wx = sfx_extloop(X, type, k > 1 ? sp1 : -1, l < W ? sq1 : -1);
+          const double q00 = QBC(k1, l1), q01 = QBC(k1, l2), q10 = QBC(k2, l1), q11 = QBC(k2, l2);
+          const double q12 = QBC(k2, l3), q21 = QBC(k3, l2), q22 = QBC(k3, l3), q23 = QBC(k3, l4), q32 = QBC(k4, l3);
+          double o = q5[k - 1] * q3[l + 1] * wx;
+          {
+            double oi = q00 * w00;
+            oi += ((e2l ? q01 : 0.0) * w01 + (e2k ? q10 : 0.0) * w10) * WB[1];
+            oi += ((e2k && e2l) ? q11 : 0.0) * w11;
+            oi += ((e2k && e3l) ? q12 : 0.0) * w12 + ((e3k && e2l) ? q21 : 0.0) * w21;
+            oi += ((e3k && e3l) ? q22 : 0.0) * w22;
+            oi += (WIL[5] * WN[1] * w23o) * (((e3k && e4l) ? q23 : 0.0) * w23 + ((e4k && e3l) ? q32 : 0.0) * w32);
+            double gg = 0.0, gg2 = 0.0;
 #pragma unroll
-              for (int u = 6; u <= 30; u += 2) {
-                gg += H[u - 4] * WIL[u];
-                if (u + 1 <= 30) gg2 += H[u - 3] * WIL[u + 1];
-              }
-              o += (gg + gg2) * X->mismatchI[rt][sq1][sp1];
+            for (int u = 6; u <= 30; u += 2) {
+              gg += H[u - 4] * WIL[u];
+              if (u + 1 <= 30) gg2 += H[u - 3] * WIL[u + 1];
             }
+            oi += (gg + gg2) * wI;
+            if (e1) o += oi;
           }
+          if (!type) o = 0.0;
           ZP[k] = o;
         }
       } else if (team == 1) {
@@ -461,9 +479,11 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
             if (u & 1) gb2 += t; else gb += t;
           }
           ZP[VW + k] = (gb + gb2) * (type > 2 ? xTAU : 1.0);  // rtype(type) > 2 <=> type > 2
+          ZP[4 * VW + k] = r1_part(0);
         }
       } else if (team == 2) {
         if (valid) {
+          r1_half = r1_part(1);
           const int type = PAIR(S[k], S[l]);
           const int rt = sfd_rtype(type);
           const int sp1 = S[k - 1], sq1 = S[l + 1];
@@ -508,18 +528,6 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
             }
           }
           ZP[3 * VW + k] = (ms + ms2) * sfx_mlstem(X, type, sp1, sq1);
-          // R1 of the next column l-1: closers (k, m), m >= l+5, right part qm[l, m-1]
-          double r1 = 0.0, r1b = 0.0;
-          const double *fW = FAC + 1250 + SF_PK_CODE(FWD[k]);
-          int m = l + SFD_TURN + 2;
-          for (; m + 3 <= W; m += 4) {
-            r1 += QBC(k, m) * fW[SF_PK_ROW(BWD[m])] * QMD(m - 1 - l, l) +
-                  QBC(k, m + 2) * fW[SF_PK_ROW(BWD[m + 2])] * QMD(m + 1 - l, l);
-            r1b += QBC(k, m + 1) * fW[SF_PK_ROW(BWD[m + 1])] * QMD(m - l, l) +
-                   QBC(k, m + 3) * fW[SF_PK_ROW(BWD[m + 3])] * QMD(m + 2 - l, l);
-          }
-          for (; m <= W; m++) r1 += QBC(k, m) * fW[SF_PK_ROW(BWD[m])] * QMD(m - 1 - l, l);
-          R1n[k] = r1 + r1b;
         }
       }
       __syncthreads();
@@ -535,8 +543,10 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
         DERP(2, l)[k] = (type > 2) ? o * xTAU : o;
         const double w = type ? o * X->MLclosing * sfx_mlstem(X, sfd_rtype(type), sj1, si1) : 0.0;
         const double r0 = w + xMLbase * R0c[k];
+        const double r1 = r1_half + ZP[4 * VW + k];
         R0n[k] = r0;
-        R01n[k] = r0 + R1n[k];
+        R1n[k] = r1;
+        R01n[k] = r0 + r1;
         const double p = o * qbkl / Z;
         mbd += p * (1.0 - p);
         if (p > 0.5) {

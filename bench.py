@@ -42,7 +42,10 @@ def cpu_baseline(eng, seq, W, step, r, kind, seed, budget_s=15.0):
     from scanfold_amd import params
     oracle.build()
     oracle.set_params(params.default_params())
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0)) or 1  # the threads this process may actually run on
+    except AttributeError:
+        cores = os.cpu_count() or 1
 
     def run(n_win):
         rows = np.frombuffer(b"NACGU", dtype=np.uint8)[eng.shuffle_windows(seq, W, step, 0, n_win, r, kind, seed)]

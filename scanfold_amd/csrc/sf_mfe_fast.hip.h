@@ -36,6 +36,7 @@
 // sets whose entries exceed SF_FAST_MAXPARAM in magnitude are routed to the int32 kernel entirely.
 #pragma once
 #include "sf_energy.h"
+#include "sf_pk16.h"
 
 #define SF_FAST_NR 34
 #define SF_INF16 30000
@@ -201,22 +202,30 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
       }
     }
   } else {
-    // all sizes exist: fetch in batches (the LDS queue holds 15 reads per wave), then update in descending u
+    // all sizes exist.  H[x] and H[x+1] (x even) share a register, so two sizes are updated by ONE packed
+    // min / saturating add / min (v_pk_*_i16): the four candidates are packed pairwise (one v_perm each), the
+    // asymmetry terms of both sizes are one aligned 32-bit read of the int16 table.  Descending order, so
+    // HP[p-1] still holds the enclosed cell's minima.  Size 30 (x = 26) has no partner.
+    {
+      const int16_t *row = X.CI + ROW(30) + i0;
+      const int e = sfd_min(row[3], row[29]) + SF_UNI(X.uNIN, 26);
+      HSET(26, sfd_min(e, HGET(24)));
+    }
 #pragma unroll
-    for (int ub = 30; ub >= 6; ub -= 5) {
-      int e1[5], e2[5], nn[5];
+    for (int pb = 12; pb >= 1; pb -= 3) {  // batches of three pairs = 12 candidate reads + 3 term reads in flight
+      uint32_t e1[3], e2[3], nn[3];
 #pragma unroll
-      for (int k = 0; k < 5; k++) {
-        const int u = ub - k;
-        const int16_t *row = X.CI + ROW(u) + i0;
-        e1[k] = row[3];
-        e2[k] = row[u - 1];
-        nn[k] = SF_UNI(X.uNIN, u - 4);
+      for (int k = 0; k < 3; k++) {
+        const int u = 2 * (pb - k) + 4;
+        const int16_t *ra = X.CI + ROW(u) + i0, *rb = X.CI + ROW(u + 1) + i0;
+        e1[k] = sf_pk(ra[3], rb[3]);          // u1 = 2
+        e2[k] = sf_pk(ra[u - 1], rb[u]);      // u2 = 2
+        nn[k] = sf_ldw(X.uNIN + (u - 4));
       }
 #pragma unroll
-      for (int k = 0; k < 5; k++) {
-        const int u = ub - k;
-        HSET(u - 4, sfd_min(sfd_min(e1[k], e2[k]) + nn[k], HGET(u - 6)));
+      for (int k = 0; k < 3; k++) {
+        const int pp = pb - k;
+        HP[pp] = sf_pkmin(sf_pkadd(sf_pkmin(e1[k], e2[k]), nn[k]), HP[pp - 1]);
       }
     }
   }
@@ -292,7 +301,7 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
         // batches of two sizes = 14 LDS reads in flight
 #pragma unroll
         for (int ub = 2; ub <= 30; ub += 2) {
-          int b1[2], b2[2], n1[2], n2[2], tb[2], tn[2], ti[2];
+          int b1[2], b2[2], n1[2], n2[2], tb[2], tn[2];
 #pragma unroll
           for (int k = 0; k < 2; k++) {
             const int u = ub + k;
@@ -300,7 +309,6 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
               const int rw = ROW(u) + i0;
               b1[k] = X.CB[rw + 1]; b2[k] = X.CB[rw + 1 + u]; tb[k] = SF_UNI(X.uBUL, u);
               if (u >= 4) { n1[k] = X.C1N[rw + 2]; n2[k] = X.C1N[rw + u]; tn[k] = SF_UNI(X.uL1N, u - 1); }
-              if (u >= 6) ti[k] = SF_UNI(X.uIL, u);
             }
           }
 #pragma unroll
@@ -309,9 +317,16 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
             if (u <= 30) {
               gb = sfd_min(gb, sfd_min(b1[k], b2[k]) + tb[k]);
               if (u >= 4) g1 = sfd_min(g1, sfd_min(n1[k], n2[k]) + tn[k]);
-              if (u >= 6) gg = sfd_min(gg, HGET(u - 4) + ti[k]);
             }
           }
+        }
+        {
+          // generic minima plus loop initiation, two sizes per packed add / min (size 31 does not exist: its
+          // half of HP[13] stays INF)
+          uint32_t ggp = sf_pk(32767, 32767);
+#pragma unroll
+          for (int pp = 1; pp <= 13; pp++) ggp = sf_pkmin(ggp, sf_pkadd(HP[pp], sf_ldw(X.uIL + 2 * pp + 4)));
+          gg = sfd_min(sf_lo(ggp), sf_hi(ggp));
         }
       }
 #endif

@@ -1,0 +1,66 @@
+// sf_pk16.h — two int16 values per 32-bit register: packed minimum / saturating add (v_pk_min_i16,
+// v_pk_add_i16 clamp on gfx950) and aligned pair access to int16 tables in LDS.  Used by the Zuker kernels
+// (sf_mfe_fast.hip.h, sf_mfe_pk.hip.h); the CPU emulation build (tests/emul) has plain C equivalents.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+#include "sf_launch.h"
+
+#ifdef SF_EMUL
+static inline uint32_t sf_pk(int lo, int hi) { return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16); }
+static inline int sf_lo(uint32_t p) { return (int)(int16_t)(p & 0xffffu); }
+static inline int sf_hi(uint32_t p) { return (int)(int16_t)(p >> 16); }
+static inline int sf_sat16(int v) { return v > 32767 ? 32767 : (v < -32768 ? -32768 : v); }
+static inline uint32_t sf_pkmin(uint32_t a, uint32_t b) {
+  return sf_pk(sf_lo(a) < sf_lo(b) ? sf_lo(a) : sf_lo(b), sf_hi(a) < sf_hi(b) ? sf_hi(a) : sf_hi(b));
+}
+static inline uint32_t sf_pkadd(uint32_t a, uint32_t b) {
+  return sf_pk(sf_sat16(sf_lo(a) + sf_lo(b)), sf_sat16(sf_hi(a) + sf_hi(b)));
+}
+static inline uint32_t sf_ldw(const int16_t *p) {  // one aligned dword (the emulation checks the alignment claim)
+  if ((uintptr_t)p & 3) { fprintf(stderr, "sf_mfe_pk: misaligned dword access\n"); abort(); }
+  uint32_t v; memcpy(&v, p, 4); return v;
+}
+static inline void sf_stw(int16_t *p, uint32_t v) {
+  if ((uintptr_t)p & 3) { fprintf(stderr, "sf_mfe_pk: misaligned dword access\n"); abort(); }
+  memcpy(p, &v, 4);
+}
+static inline void sf_store_fence() {}
+#else
+typedef short sf_s2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t sf_pk(int lo, int hi) { return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16); }
+__device__ __forceinline__ int sf_lo(uint32_t p) { return (int)(int16_t)(p & 0xffffu); }
+__device__ __forceinline__ int sf_hi(uint32_t p) { return (int)p >> 16; }
+__device__ __forceinline__ uint32_t sf_pkmin(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(sf_s2, a), __builtin_bit_cast(sf_s2, b)));
+}
+__device__ __forceinline__ uint32_t sf_pkadd(uint32_t a, uint32_t b) {  // saturating
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(sf_s2, a), __builtin_bit_cast(sf_s2, b)));
+}
+__device__ __forceinline__ uint32_t sf_ldw(const int16_t *p) { return *(const uint32_t *)p; }  // p is 4-byte aligned
+__device__ __forceinline__ void sf_stw(int16_t *p, uint32_t v) { *(uint32_t *)p = v; }
+__device__ __forceinline__ void sf_store_fence() { asm volatile("" ::: "memory"); }  // keeps two b16 stores apart
+#endif
+// the pair (p[0], p[1]); odd = parity of p's int16 index, known at compile time after unrolling
+__device__ __forceinline__ uint32_t sf_ld2(const int16_t *p, const int odd) {
+  if (odd) {
+    const uint32_t d0 = sf_ldw(p - 1), d1 = sf_ldw(p + 1);
+    return (d0 >> 16) | (d1 << 16);
+  }
+  return sf_ldw(p);
+}
+// the same with a wave-uniform parity only known at run time
+__device__ __forceinline__ uint32_t sf_ld2r(const int16_t *p, const int odd) {
+  const uint32_t d0 = sf_ldw(p - odd), d1 = sf_ldw(p - odd + 2);
+  return (uint32_t)((((uint64_t)d1 << 32) | d0) >> (odd << 4));
+}
+__device__ __forceinline__ void sf_st2(int16_t *p, const int odd, uint32_t v) {
+  if (odd) {
+    p[0] = (int16_t)(v & 0xffffu);
+    sf_store_fence();
+    p[1] = (int16_t)(v >> 16);
+  } else {
+    sf_stw(p, v);
+  }
+}
+

@@ -172,7 +172,7 @@ struct SfFastCtx {
 template <bool G, int WT>
 __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, const int i, const bool valid,
                                              const int slot2, const int slotd, uint32_t (&HP)[14], int &ovf,
-                                             const bool final_fml, int &fpart) {
+                                             const bool final_fml, const int fnb, int &fpart) {
 // H[x] (x = size - 4) lives in the int16 halves of HP[x/2]: 14 registers instead of 27 under the 128-VGPR cap
 #define HGET(x) (((x)&1) ? ((int)HP[(x) >> 1] >> 16) : (int)(int16_t)(HP[(x) >> 1] & 0xffffu))
 #define HSET(x, v)                                                                                       \
@@ -364,11 +364,9 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
     X.CI[rbd] = SF_INF16; X.C1N[rbd] = SF_INF16; X.CB[rbd] = SF_INF16;
   }
   X.cg[SF_CGIDX(i, j)] = (int16_t)c;  // row j, column i: the exterior pass reads rows coalesced
-  // fML[i,j]: the two neighbours on diagonal d-1 are final only for the even-diagonal group (see the kernel)
-  if (final_fml && d > SFD_TURN + 1) {
-    const int fb = FBASE(d - 1);
-    f = sfd_min(f, sfd_min(X.fML[fb + i0 + 1], X.fML[fb + i0]) + X.MLbase);
-  }
+  // fML[i,j]: the two neighbours on diagonal d-1 are final only for the even-diagonal group, which gets their
+  // minimum (+MLbase) in fnb from its own fix-up of the previous step (see the kernel)
+  if (final_fml && d > SFD_TURN + 1) f = sfd_min(f, fnb);
   int dec = SF_FAST_BIG;
 #ifndef SF_ABL_DML
   {
@@ -407,10 +405,9 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
   f = sfd_min(f, dec);
   X.DMLr[(d & 3) * RW + i0] = (int16_t)(dec > SF_FAST_THRESH ? SF_INF16 : dec);
   fpart = f;
-  if (final_fml) {
-    if (f < SF_FAST_OVF) ovf = 1;
-    X.fML[FBASE(d) + i0] = (int16_t)(f > SF_FAST_THRESH ? SF_INF16 : f);
-  }
+  if (final_fml && f < SF_FAST_OVF) ovf = 1;
+  // final on the even diagonal; provisional (neighbour term still missing) on the odd one
+  X.fML[FBASE(d) + i0] = (int16_t)(f > SF_FAST_THRESH ? SF_INF16 : f);
 #undef ROW
 }
 
@@ -747,6 +744,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
     __syncthreads();
     int ovf = 0;
     uint32_t H[14];  // packed int16 pairs, see HGET/HSET
+    int fnb = SF_FAST_BIG;  // even group: min of the two fML neighbours of the next cell, + MLbase
 #pragma unroll
     for (int k = 0; k < 14; k++) H[k] = (uint32_t)SF_INF16 | ((uint32_t)SF_INF16 << 16);
 
@@ -765,8 +763,8 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
 #else
       if (__ballot(valid)) {
 #endif
-        if (d0 < SFD_MAXLOOP + 6) sf_fast_cell<true, WT>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fpart);
-        else sf_fast_cell<false, WT>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fpart);
+        if (d0 < SFD_MAXLOOP + 6) sf_fast_cell<true, WT>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart);
+        else sf_fast_cell<false, WT>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart);
       }
 #ifdef SF_STAMP
       const unsigned long long t1 = SF_T();
@@ -775,23 +773,34 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
 #ifdef SF_STAMP
       const unsigned long long t2 = SF_T();
 #endif
-      if (grp == 1 && valid) {  // fML[i,j] on the odd diagonal: add the neighbours on diagonal d-1, now final
-        const int i0 = i - 1;
-        const int fb = FBASE(d - 1);
-        const int f = sfd_min(fpart, sfd_min(X.fML[fb + i0 + 1], X.fML[fb + i0]) + X.MLbase);
-        if (f < SF_FAST_OVF) ovf = 1;
-        X.fML[FBASE(d) + i0] = (int16_t)(f > SF_FAST_THRESH ? SF_INF16 : f);
+      // fML on the odd diagonal d0+1 = its provisional value (written by the odd group) min the two neighbours on
+      // the even diagonal d0, now final.  The EVEN group does this: the only early reader of fML[d0+1] is the even
+      // group's next cell (i-1, j+1), which needs the cells i-1 and i of it — so every even lane finishes BOTH
+      // (storing only its own, i) and keeps their minimum in a register.  No second barrier: nothing else reads
+      // these entries before several later barriers (the multiloop split of d reads spans <= d-5).
+      if (grp == 0 && valid) {
+        const int d1 = d0 + 1;
+        const int fbd = FBASE(d1), fbe = FBASE(d0);
+        int g[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const int x = i - h;  // cell (x, x+d1)
+          g[h] = SF_INF16;
+          if (x >= 1 && x + d1 <= W) {
+            const int v2 = sfd_min((int)X.fML[fbd + x - 1], sfd_min(X.fML[fbe + x], X.fML[fbe + x - 1]) + X.MLbase);
+            if (v2 < SF_FAST_OVF) ovf = 1;
+            g[h] = v2 > SF_FAST_THRESH ? SF_INF16 : v2;
+            if (h == 0) X.fML[fbd + x - 1] = (int16_t)g[h];
+          }
+        }
+        fnb = sfd_min(g[0], g[1]) + X.MLbase;
       }
 #ifdef SF_STAMP
-      const unsigned long long t3 = SF_T();
-#endif
-      __syncthreads();
-#ifdef SF_STAMP
       if (blockIdx.x == 0 && (tid & 63) == 0) {
-        const unsigned long long t4 = SF_T();
+        const unsigned long long t3 = SF_T();
         const int w = tid >> 6;
         sf_stamp_acc[w][0] += t1 - t0; sf_stamp_acc[w][1] += t2 - t1; sf_stamp_acc[w][2] += t3 - t2;
-        sf_stamp_acc[w][3] += t4 - t3; sf_stamp_acc[w][5] += 1;
+        sf_stamp_acc[w][5] += 1;
         if (d0 >= 56) { sf_stamp_acc[w][6] += t1 - t0; sf_stamp_acc[w][7] += 1; }
       }
 #endif

@@ -845,6 +845,10 @@ static inline void sf_fast_geometry(int W, int n_cu, int n, int *grid, int *thre
   const int by_waves = 32 / (nt / 64);
   if (per_cu > by_waves) per_cu = by_waves;
   if (per_cu > 8) per_cu = 8;
+  if (const char *e = getenv("SCANFOLD_MFE_BLOCKS_PER_CU")) {  // experiments: fewer resident workgroups per CU
+    const int v = atoi(e);
+    if (v >= 1 && v < per_cu) per_cu = v;
+  }
   if (per_cu < 1) per_cu = 1;
   long long gsz = (long long)n_cu * per_cu;
   if (gsz > n) gsz = n;

@@ -22,6 +22,8 @@
 #else
 #define SF_PIN(x) asm volatile("" : "+v"(x))
 #endif
+// v of lane l (l wave-uniform, known only at run time)
+#define SF_LANE_READ(v, l) __builtin_amdgcn_readlane((v), (l))
 // a value that is the same in every lane of the wave: tell the compiler (keeps derived index math scalar)
 #define SF_WAVE_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 // lanes of one wave exchanging data through LDS: keep the compiler from moving LDS accesses across this point

@@ -153,10 +153,11 @@ struct SfFastCtx {
 };
 
 #define SF_TIDX(t, a, b) ((t)*25 + (a)*5 + (b))
-// c scratch in device memory: row j (j >= 5) holds the cells (i, j), i = 1..j-4; small enough (13.6 kB per
-// workgroup at W=120) that the whole grid's scratch stays in L2 between the fill and the exterior pass
-#define SF_CGIDX(i, j) ((((j)-5) * ((j)-4)) / 2 + (i)-1)
-#define SF_CG_ENTRIES(W) ((((W)-4) * ((W)-3)) / 2 + 8)
+// c scratch in device memory: row i (i <= W-4) holds the cells (i, j), j = i+4..W (W: the local window width);
+// small enough (13.6 kB per workgroup at W=120) that the whole grid's scratch stays in L2 between the fill and
+// the exterior pass, which reads it row by row
+#define SF_CGIDX(i, j) (((i)-1) * (W - 3) - (((i)-1) * (i)) / 2 + ((j) - (i)-4))
+#define SF_CG_ENTRIES(W) (((((W)-4) * ((W)-3)) / 2 + 8 + 1) & ~1)  // even: a workgroup's slice stays 4-byte aligned
 
 // Size-dependent terms (loop initiation, asymmetry) are the same for every lane: they are read from small LDS
 // tables with a wave-uniform address (a broadcast read).  (Keeping them spread over the lanes of a VGPR and
@@ -363,7 +364,7 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
   } else {
     X.CI[rbd] = SF_INF16; X.C1N[rbd] = SF_INF16; X.CB[rbd] = SF_INF16;
   }
-  X.cg[SF_CGIDX(i, j)] = (int16_t)c;  // row j, column i: the exterior pass reads rows coalesced
+  X.cg[SF_CGIDX(i, j)] = (int16_t)c;  // row i, column j: the exterior pass reads rows coalesced
   // fML[i,j]: the two neighbours on diagonal d-1 are final only for the even-diagonal group, which gets their
   // minimum (+MLbase) in fnb from its own fix-up of the previous step (see the kernel)
   if (final_fml && d > SFD_TURN + 1) f = sfd_min(f, fnb);
@@ -570,85 +571,146 @@ __device__ inline int sf_fast_traceback(const SfFastCtx &X, const int32_t *f5s, 
 // the odd ones.  c[.,.] of diagonal d+1 does not depend on diagonal d (an enclosed pair spans at most d-1, the
 // multiloop split of d+1 reads fML spans <= d-3), only fML[d+1] needs its two neighbours on d — so the pair
 // (d, d+1) is computed concurrently by the two groups, then group 1 adds the neighbour term after one barrier.
+// c[i,j] + ExtLoop(i,j) for every cell, from the c scratch in device memory into LDS (same triangular layout),
+// by ALL threads of the workgroup: wave w takes the rows i = w+1, w+1+nw, ...; the lanes run along a row.
+// Leaves only one add and one min per cell to the single-wave exterior sweep.
+__device__ __forceinline__ void sf_fast_ext_table(const SfFastCtx &X, const int W, const int tid, const int nthreads,
+                                                  const int16_t *tExt, int16_t *etab) {
+  const uint8_t *S = X.S;
+  const int lane = tid & 63, nw = nthreads >> 6, w = tid >> 6;
+  constexpr int RB = 8;  // rows per batch: 2*RB device-memory reads in flight per lane before anything waits
+  for (int i0 = w + 1; i0 <= W - SFD_TURN - 1; i0 += nw * RB) {
+    int cv[RB][2];
+#pragma unroll
+    for (int r = 0; r < RB; r++) {
+      const int i = i0 + r * nw;
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int j = i + SFD_TURN + 1 + lane + 64 * h;
+        cv[r][h] = (i <= W - SFD_TURN - 1 && j <= W) ? (int)X.cg[SF_CGIDX(i, j)] : SF_INF16;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RB; r++) {
+      const int i = i0 + r * nw;
+      if (i <= W - SFD_TURN - 1) {
+        const int si = S[i], sim1 = S[i - 1];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const int j = i + SFD_TURN + 1 + lane + 64 * h;
+          if (j <= W) {
+            const int type = X.tPair[si * 8 + S[j]];
+            int e = SF_INF16;
+            if (type) {
+              const int sj1 = S[j + 1];
+              int ext;
+              if (i > 1 && j < W) ext = tExt[SF_TIDX(type, sim1, sj1)];
+              else if (i > 1) ext = X.tD5[type * 5 + sim1];
+              else if (j < W) ext = X.tD3[type * 5 + sj1];
+              else ext = 0;
+              e = sfd_min(cv[r][h] + ext + (type > 2 ? X.TAU : 0), SF_INF16);
+            }
+            etab[SF_CGIDX(i, j)] = (int16_t)e;
+          }
+        }
+      }
+    }
+  }
+}
+
 // Exterior loop f5[j] = min(f5[j-1], min_i f5[i-1] + c[i,j] + ExtLoop(i,j)), the energy / overflow record and
-// (for native windows) the traceback: ONE wave, after the fill.  Lane l owns i = l+1, l+65, ...; f5[i-1] sits
-// in its registers, c rows stream from device memory (one batch ahead), the minimum over i is a DPP wave
-// minimum.  No workgroup barrier inside.  NQ = rows per lane (ceil(W/64)).
+// (for native windows) the traceback: ONE wave, after the fill.  No workgroup barrier inside.
+// NQ = columns per lane (ceil(W/64)).  etab: c[i,j] + ExtLoop(i,j), laid out like the c scratch, prepared in LDS
+// by the whole workgroup (sf_fast_ext_table) — or null, then the terms are looked up here from the scratch.
 template <int NQ>
 __device__ __forceinline__ void sf_fast_exterior(const SfFastCtx &X, const int W, const int lane, const int seq,
-                                                 int32_t *f5s, const int16_t *tExt, const int32_t *flag,
+                                                 int32_t *f5s, const int16_t *tExt, const int16_t *etab,
+                                                 const int32_t *flag,
                                                  int16_t *stack_area, char *dbL, int32_t *__restrict__ out,
                                                  int *__restrict__ ovf_cnt, int *__restrict__ ovf_list,
                                                  const int trace_stride, char *__restrict__ db_out,
                                                  int *__restrict__ status) {
   const uint8_t *S = X.S;
   const uint8_t *tPair = X.tPair;
-  int f5r[NQ], si[NQ], sim1[NQ];
+  // Lane l owns the columns j = l+1, l+65, ...: P[q] = min over the closing rows i seen so far of
+  // f5[i-1] + c[i,j] + ExtLoop(i,j).  Rows are visited in ascending order; f5[i-1] = min(f5[i-2], P of column
+  // i-1) is final by then (column i-1 only has rows <= i-5), so one step is: fetch that P from its lane
+  // (v_readlane), one coalesced row of c (fetched a few rows ahead), one table look-up and a min per lane.
+  // No reduction across lanes anywhere.
+  int P[NQ], sj[NQ], sj1[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; q++) {
-    const int i = lane + 64 * q + 1;
-    f5r[q] = 0;
-    si[q] = i <= W ? S[i] : 0;
-    sim1[q] = i <= W ? S[i - 1] : 0;
+    const int j = lane + 64 * q + 1;
+    P[q] = SF_FAST_BIG * 2;
+    sj[q] = j <= W ? S[j] : 0;
+    sj1[q] = j <= W ? S[j + 1] : 0;
   }
-  int f5prev = 0;
+  int f5prev = 0;  // f5[i-1] while row i is processed
+  const bool want_trace = db_out && (seq % trace_stride) == 0;  // only the traceback reads f5s[]
   if (lane == 0) f5s[0] = 0;
-  constexpr int RB = 8;  // rows of c fetched per batch: one memory round trip per RB values of j
+  auto column_min = [&](const int jf) -> int {  // P of column jf, from the lane that owns it
+    const int l = (jf - 1) & 63, q = (jf - 1) >> 6;
+    int v = SF_LANE_READ(P[0], l);
+#pragma unroll
+    for (int qq = 1; qq < NQ; qq++) {
+      const int vq = SF_LANE_READ(P[qq], l);
+      if (q == qq) v = vq;
+    }
+    return v;
+  };
+  constexpr int PF = 8;  // rows of c in flight
+  int cb[PF][NQ];
+  auto load_row = [&](const int i, int(&dst)[NQ]) {
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+      const int j = lane + 64 * q + 1;
+      dst[q] = (i <= W - SFD_TURN - 1 && j <= W && i + SFD_TURN + 1 <= j) ? (int)(etab ? etab : X.cg)[SF_CGIDX(i, j)] : SF_INF16;
+    }
+  };
+#pragma unroll
+  for (int k = 0; k < PF; k++) load_row(1 + k, cb[k]);
 #ifdef SF_ABL_F5
-  for (int j0 = W; j0 <= W; j0 += RB) {
+  for (int i0 = W; i0 <= W - SFD_TURN - 1; i0 += PF) {
 #else
-  for (int j0 = 1; j0 <= W; j0 += RB) {
+  for (int i0 = 1; i0 <= W - SFD_TURN - 1; i0 += PF) {
 #endif
-    int cbuf[RB][NQ];
 #pragma unroll
-    for (int k = 0; k < RB; k++)
+    for (int k = 0; k < PF; k++) {
+      const int i = i0 + k;
+      if (i <= W - SFD_TURN - 1) {
+        if (i >= 2) {  // f5[i-1]
+          f5prev = sfd_min(f5prev, column_min(i - 1));
+          if (want_trace && lane == 0) f5s[i - 1] = f5prev;
+        }
+        if (etab) {
 #pragma unroll
-      for (int q = 0; q < NQ; q++) {
-        const int i = lane + 64 * q + 1, j = j0 + k;
-        cbuf[k][q] = (j <= W && i + SFD_TURN + 1 <= j) ? (int)X.cg[SF_CGIDX(i, j)] : SF_INF16;
-      }
-    // f5[j] needs f5[i-1] only for i <= j-4, so four consecutive j are independent up to the running
-    // minimum: their candidate minima (and wave reductions) are computed side by side, then chained
+          for (int q = 0; q < NQ; q++) P[q] = sfd_min(P[q], f5prev + cb[k][q]);
+        } else {
+        const int si = S[i], sim1 = S[i - 1];
 #pragma unroll
-    for (int kb = 0; kb < RB; kb += 4) {
-      int vals[4];
-#pragma unroll
-      for (int kk = 0; kk < 4; kk++) {
-        const int k = kb + kk, j = j0 + k;
-        int val = SF_FAST_BIG * 2;
-        if (j <= W) {
-          const int sj = S[j], sj1 = S[j + 1];
-#pragma unroll
-          for (int q = 0; q < NQ; q++) {
-            const int i = lane + 64 * q + 1;
-            if (i + SFD_TURN + 1 <= j) {
-              const int type = tPair[si[q] * 8 + sj];
-              if (type) {
-                int ext;
-                if (i > 1 && j < W) ext = tExt[SF_TIDX(type, sim1[q], sj1)];
-                else if (i > 1) ext = X.tD5[type * 5 + sim1[q]];
-                else if (j < W) ext = X.tD3[type * 5 + sj1];
-                else ext = 0;
-                val = sfd_min(val, f5r[q] + cbuf[k][q] + ext + (type > 2 ? X.TAU : 0));
-              }
+        for (int q = 0; q < NQ; q++) {
+          const int j = lane + 64 * q + 1;
+          if (j <= W && i + SFD_TURN + 1 <= j) {
+            const int type = tPair[si * 8 + sj[q]];
+            if (type) {
+              int ext;
+              if (i > 1 && j < W) ext = tExt[SF_TIDX(type, sim1, sj1[q])];
+              else if (i > 1) ext = X.tD5[type * 5 + sim1];
+              else if (j < W) ext = X.tD3[type * 5 + sj1[q]];
+              else ext = 0;
+              P[q] = sfd_min(P[q], f5prev + cb[k][q] + ext + (type > 2 ? X.TAU : 0));
             }
           }
         }
-        vals[kk] = sf_wave_min(val);
-      }
-#pragma unroll
-      for (int kk = 0; kk < 4; kk++) {
-        const int j = j0 + kb + kk;
-        if (j <= W) {
-          const int f5j = sfd_min(f5prev, vals[kk]);
-          f5prev = f5j;
-          if (lane == 0) f5s[j] = f5j;
-#pragma unroll
-          for (int q = 0; q < NQ; q++)
-            if (lane + 64 * q == j) f5r[q] = f5j;
         }
+        load_row(i + PF, cb[k]);
       }
     }
+  }
+  // the last columns: every row has been seen
+  for (int jf = sfd_max(W - SFD_TURN - 1, 1); jf <= W; jf++) {
+    f5prev = sfd_min(f5prev, column_min(jf));
+    if (want_trace && lane == 0) f5s[jf] = f5prev;
   }
   SF_WAVE_SYNC();  // f5s[] was written by lane 0, the traceback reads it from every lane
   const int over = flag[0] || f5prev < SF_FAST_OVF;
@@ -712,7 +774,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
   int16_t *tExt = (int16_t *)(smem + Lo.off_ci + (((W + 1) * 4 + 3) & ~3));
 
   const int tid = threadIdx.x;
-  X.cg = cg_all + (size_t)blockIdx.x * SF_CG_ENTRIES(W);  // c by (row j, column i), triangular
+  X.cg = cg_all + (size_t)blockIdx.x * SF_CG_ENTRIES(W);  // c by (row i, column j), triangular
   // parameter tables -> LDS, once per workgroup
   for (int x = tid; x < 200; x += NT) {
     tab[x] = F->mmI[x]; tab[200 + x] = F->mm1n[x]; tab[400 + x] = F->mm23[x]; tab[600 + x] = F->mmM[x];
@@ -817,9 +879,22 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
     if (ovf) flag[0] = 1;
     for (int x = tid; x < 200; x += NT) tExt[x] = F->mmExt[x];
     __syncthreads();
+    // The rolling tables are dead now.  When a table of c + ExtLoop fits into the CI + C1N areas behind f5[] and the
+    // mismatchExt table, the whole workgroup builds it in LDS (sf_fast_ext_table), so the single-wave exterior
+    // sweep neither waits for device memory nor looks anything up.
+    int16_t *etab = nullptr;
+    {
+      const int e_off = (int)(((char *)tExt - smem) + 400 + 3) & ~3;
+      if (e_off + SF_CG_ENTRIES(W) * 2 <= Lo.off_cb) {
+        etab = (int16_t *)(smem + e_off);
+        sf_fast_ext_table(X, W, tid, NT, tExt, etab);
+      }
+    }
+    __syncthreads();
     if (tid < 64)
-      sf_fast_exterior<NG / 64>(X, W, tid, seq, f5s, tExt, flag, (int16_t *)(smem + Lo.off_c1n), (char *)(smem + Lo.off_cb),
-                                out, ovf_cnt, ovf_list, trace_stride, db_out, status);
+      sf_fast_exterior<NG / 64>(X, W, tid, seq, f5s, tExt, etab, flag, (int16_t *)(smem + Lo.off_cb),
+                      (char *)(smem + Lo.off_cb + ((3 * (W + 8) * 2 + 3) & ~3)), out, ovf_cnt, ovf_list, trace_stride,
+                      db_out, status);
 #ifdef SF_STAMP
     if (blockIdx.x == 0 && (tid & 63) == 0) sf_stamp_acc[tid >> 6][4] += SF_T() - tf0;
 #endif

@@ -468,9 +468,22 @@ __global__ __launch_bounds__(128, 2) void sf_mfe_pk_kernel(const uint8_t *__rest
     if (ovf) flag[0] = 1;
     for (int x = tid; x < 200; x += NT) tExt[x] = F->mmExt[x];
     __syncthreads();
+    // The rolling tables are dead now.  When a table of c + ExtLoop fits into the CI + C1N areas behind f5[] and the
+    // mismatchExt table, the whole workgroup builds it in LDS (sf_fast_ext_table), so the single-wave exterior
+    // sweep neither waits for device memory nor looks anything up.
+    int16_t *etab = nullptr;
+    {
+      const int e_off = (int)(((char *)tExt - smem) + 400 + 3) & ~3;
+      if (e_off + SF_CG_ENTRIES(W) * 2 <= Lo.off_cb) {
+        etab = (int16_t *)(smem + e_off);
+        sf_fast_ext_table(X, W, tid, NT, tExt, etab);
+      }
+    }
+    __syncthreads();
     if (tid < 64)
-      sf_fast_exterior<2>(X, W, tid, seq, f5s, tExt, flag, (int16_t *)(smem + Lo.off_c1n), (char *)(smem + Lo.off_cb),
-                          out, ovf_cnt, ovf_list, trace_stride, db_out, status);
+      sf_fast_exterior<2>(X, W, tid, seq, f5s, tExt, etab, flag, (int16_t *)(smem + Lo.off_cb),
+                      (char *)(smem + Lo.off_cb + ((3 * (W + 8) * 2 + 3) & ~3)), out, ovf_cnt, ovf_list, trace_stride,
+                      db_out, status);
   }
 }
 

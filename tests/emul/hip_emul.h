@@ -158,6 +158,7 @@ inline T atomicOr(T *p, T v) { T o = *p; *p = o | v; return o; }
 #define SF_SCHED_GROUP(mask, n) ((void)0)
 #define SF_SCHED_FENCE() ((void)0)
 #define SF_PIN(x) ((void)0)
+#define SF_LANE_READ(v, l) __shfl((v), (l))
 
 /* dynamic shared memory */
 #define SF_DYN_SMEM(name) char *name = sfemul::g_blk->smem.data()

@@ -100,7 +100,8 @@ int sf_scan_dev(const uint8_t *d_transcript, int L, int W, int step, int win_beg
                 char *d_centroid, double *d_ens_div, double *d_ens_dG, void *stream);
 
 /* Diagnostics: 0 = automatic (LDS int16 kernel with int32 fallback), 1 = always the int32 kernel,
- * 2 = the packed two-cells-per-lane LDS kernel for W <= 128 (experimental, slower in round 1).
+ * 2 = the packed two-cells-per-lane LDS kernel for W <= 128 (experimental, slower in round 1),
+ * 3 = the two-folds-per-workgroup LDS kernel for W <= 128 (interleaved tables, packed int16).
  * Results are identical in every mode; tests use it to cross-check the kernels. */
 int sf_set_kernel_mode(int mode);
 

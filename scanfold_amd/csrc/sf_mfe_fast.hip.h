@@ -149,6 +149,7 @@ struct SfFastCtx {
   int16_t *cg;
   int W, TAU, MLbase, MLclosing, MLintern;
   int fml_pad;  // 1: every diagonal of the fML triangle starts at an even index (sf_mfe_pk.hip.h)
+  int fst;      // element stride of fML (2 when two folds are interleaved, sf_mfe_dual.hip.h)
   const int16_t *uNIN, *uIL, *uL1N, *uBUL;  // size-dependent terms, LDS copies (uniform reads)
 };
 
@@ -442,7 +443,7 @@ __device__ inline int sf_fast_traceback(const SfFastCtx &X, const int32_t *f5s, 
 #define TC(i, j) ((int)X.cg[SF_CGIDX(i, j)])
 // diagonals of odd length are followed by one pad entry when X.fml_pad is set
 #define SF_FPADCNT(dd) ((((dd) + (W & 1)) >> 1) - 2)
-#define TF(i, j) (((j) - (i) < SFD_TURN + 1) ? SF_INF16 : (int)X.fML[FBASE((j) - (i)) + (X.fml_pad ? SF_FPADCNT((j) - (i)) : 0) + (i)-1])
+#define TF(i, j) (((j) - (i) < SFD_TURN + 1) ? SF_INF16 : (int)X.fML[(FBASE((j) - (i)) + (X.fml_pad ? SF_FPADCNT((j) - (i)) : 0) + (i)-1) * X.fst])
 #define TPAIR(i, j) ((int)X.tPair[S[i] * 8 + S[j]])
   for (int x = lane; x < W; x += 64) dbL[x] = '.';
   int sp = 0, bad = 0;
@@ -767,7 +768,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
   int32_t *flag = (int32_t *)(smem + Lo.off_flag);
   uint8_t *S = (uint8_t *)(smem + Lo.off_S);
   X.S = S;
-  X.D = D; X.F = F; X.W = W; X.fml_pad = 0;
+  X.D = D; X.F = F; X.W = W; X.fml_pad = 0; X.fst = 1;
   X.TAU = D->P.TerminalAU; X.MLbase = D->P.MLbase; X.MLclosing = D->P.MLclosing; X.MLintern = D->P.MLintern[1];
   // exterior pass aliases (the rolling CI area is dead by then)
   int32_t *f5s = (int32_t *)(smem + Lo.off_ci);

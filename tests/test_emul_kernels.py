@@ -34,13 +34,17 @@ def test_fast_and_full_mfe_kernels_match_oracle(emul, oracle):
         assert (emul.mfe_batch(arr) == ref).all(), W
         emul.set_kernel_mode(2)  # packed two-cells-per-lane kernel (W <= 128; the emulation aborts on a misaligned pair read)
         assert (emul.mfe_batch(arr) == ref).all(), W
+        emul.set_kernel_mode(3)  # two folds per workgroup, interleaved tables (W <= 128)
+        assert (emul.mfe_batch(arr) == ref).all(), W
+        assert (emul.mfe_batch(arr[: n - 1]) == ref[: n - 1]).all(), W  # odd count: the last pair is one fold twice
         emul.set_kernel_mode(0)
 
 
-def test_packed_kernel_odd_widths_and_traceback(emul, oracle):
+@pytest.mark.parametrize("mode", [2, 3])
+def test_packed_kernels_odd_widths_and_traceback(emul, oracle, mode):
     emul.load_params(params.default_params())
     rng = np.random.default_rng(11)
-    emul.set_kernel_mode(2)
+    emul.set_kernel_mode(mode)
     try:
         for W in (16, 61, 99, 127, 128):
             arr = random_seqs(rng, 3, W)

@@ -99,6 +99,12 @@ int sf_scan_dev(const uint8_t *d_transcript, int L, int W, int step, int win_beg
                 int shuffle_kind, uint64_t seed, unsigned flags, int32_t *d_energies, char *d_structure,
                 char *d_centroid, double *d_ens_div, double *d_ens_dG, void *stream);
 
+/* Maximum base-pair span of the folding model.  Replaces md.max_bp_span = args.span (ScanFold.py:214-215; the
+ * Scan stage script has no such flag): base pairs (i, j) with j - i + 1 > span do not exist, in the MFE fill, the
+ * partition function and the traceback.  span <= 0 removes the limit (the default).  Survives sf_params_load.
+ * SURVEY.md 8(f) rank 1, first item; hard constraints and temperatures != 37 C are not implemented. */
+int sf_set_max_bp_span(int span);
+
 /* Diagnostics: 0 = automatic (LDS int16 kernel with int32 fallback), 1 = always the int32 kernel,
  * 2 = the packed two-cells-per-lane LDS kernel for W <= 128 (experimental, slower in round 1),
  * 3 = the two-folds-per-workgroup LDS kernel for W <= 128 (interleaved tables, packed int16).

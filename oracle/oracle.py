@@ -48,6 +48,11 @@ def set_params(paramset):
         raise RuntimeError("sfo_set_params rc=%d" % rc)
 
 
+def set_max_bp_span(span):
+    """RNA.md().max_bp_span: pairs (i, j) with j - i + 1 > span do not exist; <= 0 removes the limit."""
+    lib().sfo_set_max_bp_span(int(span or 0))
+
+
 def mfe(seq, structure=True):
     s = seq.encode()
     e = ctypes.c_int()

@@ -170,7 +170,13 @@ static void seq_free(seq_t *q) {
   free(q->S);
   free(q->str);
 }
-static inline int ptype(const seq_t *q, int i, int j) { return pair_tab[q->S[i]][q->S[j]]; }
+/* RNA.md().max_bp_span (ScanFold.py:214-215; [EXT] ViennaRNA: a pair (i,j) needs j - i + 1 <= max_bp_span); <= 0: none */
+static int g_max_bp_span = 0;
+int sfo_set_max_bp_span(int span) { g_max_bp_span = span > 0 ? span : 0; return 0; }
+static inline int ptype(const seq_t *q, int i, int j) {
+  if (g_max_bp_span > 0 && j - i + 1 > g_max_bp_span) return 0;
+  return pair_tab[q->S[i]][q->S[j]];
+}
 
 /* ---------- loop energies ---------- */
 static int special_lookup(const char (*tab)[8], int cnt, const char *s, int len) {

@@ -3,7 +3,8 @@
 reference call sites: RNA.md() ScanFold-Scan.py:70, ScanFold.py:212; RNA.fold_compound(seq, md) Scan:382;
 fc.mfe() :385; fc.pf() :383; RNA.pf_fold(seq) :384; fc.centroid() :388; fc.mean_bp_distance() :389;
 RNA.fold(seq) :245.  Energies come back as ViennaRNA returns them: (float)dcal / 100 widened to a Python float.
-Not provided (out of this path's scope): hard/soft constraints, max_bp_span, duplexfold, plotting.
+md.max_bp_span (ScanFold.py:214-215) is honoured (sf_set_max_bp_span).
+Not provided (out of this path's scope): hard/soft constraints, duplexfold, plotting.
 """
 import numpy as np
 
@@ -23,8 +24,11 @@ def _check_md(model):
         if float(model.temperature) != eng.params.temperature:
             raise NotImplementedError("temperature %s C: parameter set valid at %s C only"
                                       % (model.temperature, eng.params.temperature))
-        if getattr(model, "max_bp_span", -1) not in (-1, 0, None):
-            raise NotImplementedError("max_bp_span is not supported")
+    span = getattr(model, "max_bp_span", -1) if model is not None else -1
+    span = int(span) if span not in (None, -1) and int(span) > 0 else 0
+    if span != getattr(eng, "_span", 0):  # the model is global state of the engine, like RNA's md defaults
+        eng.set_max_bp_span(span)
+        eng._span = span
     return eng
 
 

@@ -43,6 +43,7 @@ _EXPORTS = {
                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                    ctypes.c_void_p]),
     "sf_set_kernel_mode": (ctypes.c_int, [ctypes.c_int]),
+    "sf_set_max_bp_span": (ctypes.c_int, [ctypes.c_int]),
     "sf_prof_reset": (ctypes.c_int, []),
     "sf_prof_get": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64),
                                    ctypes.POINTER(ctypes.c_int64)]),
@@ -199,6 +200,10 @@ class Engine:
 
     def set_kernel_mode(self, mode):
         self._check(self.lib.sf_set_kernel_mode(int(mode)))
+
+    def set_max_bp_span(self, span):
+        """RNA.md().max_bp_span (ScanFold.py:214-215): pairs (i, j) with j - i + 1 > span do not exist; <= 0 = no limit."""
+        self._check(self.lib.sf_set_max_bp_span(int(span or 0)))
 
     def prof_reset(self):
         self._check(self.lib.sf_prof_reset())

@@ -4,6 +4,7 @@
 // (ScanFold-Scan.py:73-77,256,274); here one process owns one GPU and every call is a few batched launches
 // on one HIP stream.  No CPU compute path exists in this file: without a GPU sf_init fails.
 #include <math.h>
+#include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -51,6 +52,7 @@ struct Ctx {
   int mfe_kernel = 0;  // 0: one cell per lane (sf_mfe_fast.hip.h); 1: two cells per lane, packed int16, W <= 128
                        // (sf_mfe_pk.hip.h; kernel mode 2 or SCANFOLD_MFE_KERNEL=pk); 2: two folds per workgroup with
                        // interleaved tables (sf_mfe_dual.hip.h; kernel mode 3 or SCANFOLD_MFE_KERNEL=dual)
+  int max_bp_span = 0;  // RNA.md().max_bp_span; <= 0: no limit
   int pf_kernel = 0;  // 0: LDS-resident kernel where it fits; 1: device-memory tables (SCANFOLD_PF_KERNEL=global)
   int pf_blocks_per_cu = 4;  // 256 VGPRs per thread: 2 waves per SIMD
 } g;
@@ -351,6 +353,7 @@ int sf_params_load(const void *blob, size_t nbytes, double temperature_c) {
   static SfDevParamsPF X;
   static SfFastParams F;
   build_dev_params(P, D, X);
+  D.max_pair_dist = g.max_bp_span > 0 ? g.max_bp_span - 1 : 0x7fffffff;
   sf_fast_build_params(D, F);
   g.fast_ok = F.fast_ok;
   HIPCHK(hipStreamSynchronize(g.stream));
@@ -525,6 +528,17 @@ int sf_scan(const uint8_t *transcript, int L, int W, int step, int win_begin, in
   HIPCHK(hipMemcpyAsync(&st, g.status.p, sizeof(int), hipMemcpyDeviceToHost, g.stream));
   HIPCHK(hipStreamSynchronize(g.stream));
   return st ? SF_ERR_INTERNAL : SF_OK;
+}
+
+int sf_set_max_bp_span(int span) {
+  if (!g.init) return SF_ERR_NOT_INIT;
+  g.max_bp_span = span > 0 ? span : 0;
+  if (g.have_params) {  // patch the field of the resident model
+    const int32_t md = g.max_bp_span > 0 ? g.max_bp_span - 1 : 0x7fffffff;
+    HIPCHK(hipStreamSynchronize(g.stream));
+    HIPCHK(hipMemcpy((char *)g.dP + offsetof(SfDevParams, max_pair_dist), &md, sizeof md, hipMemcpyHostToDevice));
+  }
+  return SF_OK;
 }
 
 int sf_set_kernel_mode(int mode) {

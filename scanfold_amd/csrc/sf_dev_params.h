@@ -14,6 +14,7 @@ struct SfDevParams {
   uint32_t tri_key[SF_NSPECIAL];
   uint32_t hexa_key[SF_NSPECIAL];
   int32_t pair[8][8];                 // pair type of two nucleotide codes
+  int32_t max_pair_dist;              // largest j - i a base pair may have: RNA.md().max_bp_span - 1 (ScanFold.py:214-215); INT32_MAX = no limit
 };
 
 // Boltzmann weights for the partition function at the blob's temperature.

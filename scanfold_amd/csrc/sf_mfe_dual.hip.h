@@ -230,7 +230,7 @@ __device__ __forceinline__ void sf_dual_cell(const SfFastCtx &XA, const SfFastCt
     const uint8_t *S = X.S;
     int c = SF_INF16, f = SF_FAST_BIG;
     int pI = SF_INF16, p1n = SF_INF16, pb = SF_INF16;
-    const int type = X.tPair[S[i] * 8 + S[j]];
+    const int type = d <= X.maxd ? X.tPair[S[i] * 8 + S[j]] : 0;
     if (type) {
       const int si1 = S[i + 1], sj1 = S[j - 1];
       const int TAU = X.TAU;
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(SF_DUAL_NT, 2) void sf_mfe_dual_kernel(const uint8_
   XA.tPair = tPair;
   XA.tD5 = tab + 1096; XA.tD3 = tab + 1136;
   XA.S = S0;
-  XA.D = D; XA.F = F; XA.W = W; XA.fml_pad = 0; XA.fst = 2;
+  XA.D = D; XA.F = F; XA.W = W; XA.fml_pad = 0; XA.fst = 2; XA.maxd = D->max_pair_dist;
   XA.TAU = D->P.TerminalAU; XA.MLbase = D->P.MLbase; XA.MLclosing = D->P.MLclosing; XA.MLintern = D->P.MLintern[1];
   XA.uNIN = nullptr; XA.uIL = nullptr; XA.uL1N = nullptr; XA.uBUL = nullptr;
   XA.cg = cg_all + (size_t)blockIdx.x * 2 * SF_CG_ENTRIES(W);

@@ -39,6 +39,12 @@
 #include "sf_pk16.h"
 
 #define SF_FAST_NR 34
+// 1: the workgroup first builds c + ExtLoop for all cells in LDS (sf_fast_ext_table) and the exterior sweep reads
+// that; 0: the sweep reads the c scratch from device memory (L2) and looks the terms up itself.  Measured on
+// MI355X at W=120: 110.1 ms vs 109.1 ms per 262 144 folds — the table is not worth its two extra barriers.
+#ifndef SF_EXT_TABLE
+#define SF_EXT_TABLE 0
+#endif
 #define SF_INF16 30000
 #define SF_FAST_THRESH 10000
 #define SF_FAST_OVF (-12000)
@@ -149,6 +155,7 @@ struct SfFastCtx {
   int16_t *cg;
   int W, TAU, MLbase, MLclosing, MLintern;
   int fml_pad;  // 1: every diagonal of the fML triangle starts at an even index (sf_mfe_pk.hip.h)
+  int maxd;     // largest allowed j - i of a base pair (max_bp_span - 1)
   int fst;      // element stride of fML (2 when two folds are interleaved, sf_mfe_dual.hip.h)
   const int16_t *uNIN, *uIL, *uL1N, *uBUL;  // size-dependent terms, LDS copies (uniform reads)
 };
@@ -185,7 +192,7 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
   const int j = i + d, i0 = i - 1;
   const uint8_t *S = X.S;
   const int umax = G ? sfd_min(SFD_MAXLOOP, d - 2 - (SFD_TURN + 1)) : SFD_MAXLOOP;
-  const int type = X.tPair[S[i] * 8 + S[j]];
+  const int type = d <= X.maxd ? X.tPair[S[i] * 8 + S[j]] : 0;  // max_bp_span: longer pairs do not exist
   const int si1 = S[i + 1], sj1 = S[j - 1];
 // fML triangle without diagonals 0..3: base(d) = sum_{k=4}^{d-1} (W-k)
 #define FBASE(dd) (((dd)-4) * W - ((dd) * ((dd)-1) / 2 - 6))
@@ -444,7 +451,7 @@ __device__ inline int sf_fast_traceback(const SfFastCtx &X, const int32_t *f5s, 
 // diagonals of odd length are followed by one pad entry when X.fml_pad is set
 #define SF_FPADCNT(dd) ((((dd) + (W & 1)) >> 1) - 2)
 #define TF(i, j) (((j) - (i) < SFD_TURN + 1) ? SF_INF16 : (int)X.fML[(FBASE((j) - (i)) + (X.fml_pad ? SF_FPADCNT((j) - (i)) : 0) + (i)-1) * X.fst])
-#define TPAIR(i, j) ((int)X.tPair[S[i] * 8 + S[j]])
+#define TPAIR(i, j) (((j) - (i)) <= X.maxd ? (int)X.tPair[S[i] * 8 + S[j]] : 0)
   for (int x = lane; x < W; x += 64) dbL[x] = '.';
   int sp = 0, bad = 0;
   stI[0] = 1; stJ[0] = (int16_t)W; stM[0] = 0; sp = 1;
@@ -600,7 +607,7 @@ __device__ __forceinline__ void sf_fast_ext_table(const SfFastCtx &X, const int 
         for (int h = 0; h < 2; h++) {
           const int j = i + SFD_TURN + 1 + lane + 64 * h;
           if (j <= W) {
-            const int type = X.tPair[si * 8 + S[j]];
+            const int type = j - i <= X.maxd ? X.tPair[si * 8 + S[j]] : 0;
             int e = SF_INF16;
             if (type) {
               const int sj1 = S[j + 1];
@@ -692,7 +699,7 @@ __device__ __forceinline__ void sf_fast_exterior(const SfFastCtx &X, const int W
         for (int q = 0; q < NQ; q++) {
           const int j = lane + 64 * q + 1;
           if (j <= W && i + SFD_TURN + 1 <= j) {
-            const int type = tPair[si * 8 + sj[q]];
+            const int type = j - i <= X.maxd ? tPair[si * 8 + sj[q]] : 0;
             if (type) {
               int ext;
               if (i > 1 && j < W) ext = tExt[SF_TIDX(type, sim1, sj1[q])];
@@ -768,7 +775,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
   int32_t *flag = (int32_t *)(smem + Lo.off_flag);
   uint8_t *S = (uint8_t *)(smem + Lo.off_S);
   X.S = S;
-  X.D = D; X.F = F; X.W = W; X.fml_pad = 0; X.fst = 1;
+  X.D = D; X.F = F; X.W = W; X.fml_pad = 0; X.fst = 1; X.maxd = D->max_pair_dist;
   X.TAU = D->P.TerminalAU; X.MLbase = D->P.MLbase; X.MLclosing = D->P.MLclosing; X.MLintern = D->P.MLintern[1];
   // exterior pass aliases (the rolling CI area is dead by then)
   int32_t *f5s = (int32_t *)(smem + Lo.off_ci);
@@ -886,7 +893,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
     int16_t *etab = nullptr;
     {
       const int e_off = (int)(((char *)tExt - smem) + 400 + 3) & ~3;
-      if (e_off + SF_CG_ENTRIES(W) * 2 <= Lo.off_cb) {
+      if (SF_EXT_TABLE && e_off + SF_CG_ENTRIES(W) * 2 <= Lo.off_cb) {
         etab = (int16_t *)(smem + e_off);
         sf_fast_ext_table(X, W, tid, NT, tExt, etab);
       }

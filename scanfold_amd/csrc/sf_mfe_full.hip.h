@@ -60,7 +60,7 @@ __global__ void sf_mfe_full_kernel(const uint8_t *__restrict__ seqs, const int *
     for (int d = SFD_TURN + 1; d < W; d++) {
       const int i = tid + 1, j = i + d;
       if (j <= W) {
-        const int type = D->pair[S[i]][S[j]];
+        const int type = d <= D->max_pair_dist ? D->pair[S[i]][S[j]] : 0;  // max_bp_span
         int cij = SFD_INF;
         if (type) {
           int e = sfd_hairpin(D, S, i, j, type);
@@ -101,7 +101,7 @@ __global__ void sf_mfe_full_kernel(const uint8_t *__restrict__ seqs, const int *
     for (int j = 1; j <= W; j++) {
       int v = SFD_INF;
       const int i = tid + 1;
-      if (i + SFD_TURN + 1 <= j) {
+      if (i + SFD_TURN + 1 <= j && j - i <= D->max_pair_dist) {
         const int type = D->pair[S[i]][S[j]];
         if (type) v = f5s[i - 1] + FT(c, j - i, i) + sfd_extloop(D, type, i > 1 ? S[i - 1] : -1, j < W ? S[j + 1] : -1);
       }
@@ -128,7 +128,7 @@ __global__ void sf_mfe_full_kernel(const uint8_t *__restrict__ seqs, const int *
           const int fij = f5s[j];
           int kk, found = 0;
           for (kk = j - SFD_TURN - 1; kk >= 1; kk--) {
-            const int type = D->pair[S[kk]][S[j]];
+            const int type = j - kk <= D->max_pair_dist ? D->pair[S[kk]][S[j]] : 0;
             if (!type) continue;
             if (fij == f5s[kk - 1] + FT(c, j - kk, kk) +
                            sfd_extloop(D, type, kk > 1 ? S[kk - 1] : -1, j < W ? S[j + 1] : -1)) { found = 1; break; }
@@ -144,7 +144,7 @@ __global__ void sf_mfe_full_kernel(const uint8_t *__restrict__ seqs, const int *
           while (j - i > SFD_TURN + 1 && FT(fML, j - i - 1, i + 1) < SFD_INF &&
                  FT(fML, j - i, i) == FT(fML, j - i - 1, i + 1) + P.MLbase) i++;
           const int fij = FT(fML, j - i, i);
-          const int type = D->pair[S[i]][S[j]];
+          const int type = j - i <= D->max_pair_dist ? D->pair[S[i]][S[j]] : 0;
           if (type && fij == FT(c, j - i, i) + sfd_mlstem(D, type, i > 1 ? S[i - 1] : -1, j < W ? S[j + 1] : -1)) {
             have_pair = true;
           } else {

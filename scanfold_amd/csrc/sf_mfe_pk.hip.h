@@ -240,7 +240,7 @@ __device__ __forceinline__ void sf_pk_cell(const SfFastCtx &X, const SfPkUni &U,
     int c = SF_INF16, f = SF_FAST_BIG;
     int pI = SF_INF16, p1n = SF_INF16, pb = SF_INF16;
     if (valid) {
-      const int type = X.tPair[S[i] * 8 + S[j]];
+      const int type = d <= X.maxd ? X.tPair[S[i] * 8 + S[j]] : 0;
       if (type) {
         const int si1 = S[i + 1], sj1 = S[j - 1];
         const int TAU = X.TAU;
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(128, 2) void sf_mfe_pk_kernel(const uint8_t *__rest
   int32_t *flag = (int32_t *)(smem + Lo.off_flag);
   uint8_t *S = (uint8_t *)(smem + Lo.off_S);
   X.S = S;
-  X.D = D; X.F = F; X.W = W; X.fml_pad = 1; X.fst = 1;
+  X.D = D; X.F = F; X.W = W; X.fml_pad = 1; X.fst = 1; X.maxd = D->max_pair_dist;
   X.TAU = D->P.TerminalAU; X.MLbase = D->P.MLbase; X.MLclosing = D->P.MLclosing; X.MLintern = D->P.MLintern[1];
   // exterior pass aliases (the rolling CI area is dead by then)
   int32_t *f5s = (int32_t *)(smem + Lo.off_ci);
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(128, 2) void sf_mfe_pk_kernel(const uint8_t *__rest
     int16_t *etab = nullptr;
     {
       const int e_off = (int)(((char *)tExt - smem) + 400 + 3) & ~3;
-      if (e_off + SF_CG_ENTRIES(W) * 2 <= Lo.off_cb) {
+      if (SF_EXT_TABLE && e_off + SF_CG_ENTRIES(W) * 2 <= Lo.off_cb) {
         etab = (int16_t *)(smem + e_off);
         sf_fast_ext_table(X, W, tid, NT, tExt, etab);
       }

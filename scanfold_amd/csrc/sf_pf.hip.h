@@ -65,7 +65,7 @@ __global__ void sf_pf_kernel(const uint8_t *__restrict__ seqs, int n, int row_st
     for (int d = SFD_TURN + 1; d < W; d++) {
       const int i = tid + 1, j = i + d;
       if (j <= W) {
-        const int type = D->pair[S[i]][S[j]];
+        const int type = j - i <= D->max_pair_dist ? D->pair[S[i]][S[j]] : 0;
         double qbij = 0.0;
         if (type) {
           double z = sfx_hairpin(D, X, S, i, j, type);
@@ -103,7 +103,7 @@ __global__ void sf_pf_kernel(const uint8_t *__restrict__ seqs, int n, int row_st
       double v = 0.0;
       const int i = tid + 1;
       if (i + SFD_TURN + 1 <= j) {
-        const int type = D->pair[S[i]][S[j]];
+        const int type = j - i <= D->max_pair_dist ? D->pair[S[i]][S[j]] : 0;
         if (type) v = q5[i - 1] * PT(QB, j - i, i) * sfx_extloop(X, type, i > 1 ? S[i - 1] : -1, j < W ? S[j + 1] : -1);
       }
       v = sf_block_sum(v, red);
@@ -114,7 +114,7 @@ __global__ void sf_pf_kernel(const uint8_t *__restrict__ seqs, int n, int row_st
       double v = 0.0;
       const int j = tid + 1;
       if (j <= W && i + SFD_TURN + 1 <= j) {
-        const int type = D->pair[S[i]][S[j]];
+        const int type = j - i <= D->max_pair_dist ? D->pair[S[i]][S[j]] : 0;
         if (type) v = PT(QB, j - i, i) * sfx_extloop(X, type, i > 1 ? S[i - 1] : -1, j < W ? S[j + 1] : -1) * q3[j + 1];
       }
       v = sf_block_sum(v, red);
@@ -135,7 +135,7 @@ __global__ void sf_pf_kernel(const uint8_t *__restrict__ seqs, int n, int row_st
         }
         PT(A0, d, i) = a0;
         PT(A1, d, i) = a1;
-        const int type = D->pair[S[i]][S[j]];
+        const int type = j - i <= D->max_pair_dist ? D->pair[S[i]][S[j]] : 0;
         double o = 0.0, ow = 0.0;
         const double qbij = PT(QB, d, i);
         if (type && qbij != 0.0) {

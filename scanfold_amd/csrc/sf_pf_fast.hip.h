@@ -76,7 +76,7 @@ __global__ __launch_bounds__(NT) void sf_pf_fast_kernel(const uint8_t *__restric
       const bool valid = (i >= 1) && (j <= W);
       if (valid) {
         const int umax = G ? sfd_min(SFD_MAXLOOP, d - 2 - (SFD_TURN + 1)) : SFD_MAXLOOP;
-        const int type = D->pair[S[i]][S[j]];
+        const int type = j - i <= D->max_pair_dist ? D->pair[S[i]][S[j]] : 0;
         const int si1 = S[i + 1], sj1 = S[j - 1];
         // generic interior sums of this cell from those of the enclosed cell
 #ifndef SF_PFABL_UIN
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(NT) void sf_pf_fast_kernel(const uint8_t *__restric
       double val = 0.0;
       const int i = tid + 1;
       if (i + SFD_TURN + 1 <= j) {
-        const int type = D->pair[S[i]][S[j]];
+        const int type = j - i <= D->max_pair_dist ? D->pair[S[i]][S[j]] : 0;
         if (type) val = q5[i - 1] * PT(T.QB, j - i, i) * sfx_extloop(X, type, i > 1 ? S[i - 1] : -1, j < W ? S[j + 1] : -1);
       }
       val = sf_block_sum(val, red);
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(NT) void sf_pf_fast_kernel(const uint8_t *__restric
       double val = 0.0;
       const int j = tid + 1;
       if (j <= W && i + SFD_TURN + 1 <= j) {
-        const int type = D->pair[S[i]][S[j]];
+        const int type = j - i <= D->max_pair_dist ? D->pair[S[i]][S[j]] : 0;
         if (type) val = PT(T.QB, j - i, i) * sfx_extloop(X, type, i > 1 ? S[i - 1] : -1, j < W ? S[j + 1] : -1) * q3[j + 1];
       }
       val = sf_block_sum(val, red);
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(NT) void sf_pf_fast_kernel(const uint8_t *__restric
         }
         PT(T.A0, d, i) = a0;
         PT(T.A1, d, i) = a1;
-        const int type = D->pair[S[i]][S[j]];
+        const int type = j - i <= D->max_pair_dist ? D->pair[S[i]][S[j]] : 0;
         const double qbij = PT(T.QB, d, i);
         double o = 0.0;
         if (type && qbij != 0.0) {

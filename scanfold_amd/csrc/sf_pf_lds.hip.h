@@ -105,8 +105,11 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
 #define QMD(d, i) QM[DOFF(d) + (i)-1]
 #define DERP(kind, col) (DER + ((kind)*4 + ((col)&3)) * RP + SF_PFL_PAD)
 #define PAIR(a, b) PT8[(a)*8 + (b)]
+// pair type of the cell itself: none beyond RNA.md().max_bp_span
+#define OWN(a, b) (((b) - (a)) <= maxd ? PAIR(S[a], S[b]) : 0)
   const double xTAU = X->TermAU;
   const double xMLbase = X->MLbase;
+  const int maxd = D->max_pair_dist;
   // speculative (discarded or zero-weighted) reads below may land anywhere in the tables: keep them finite
   for (int x = tid; x < 2 * NC; x += SF_PFL_NT) QB[x] = 0.0;
   if (tid < 32) {
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
       double qm_half = 0.0;  // team 2's half of qm[i,j-1], completed after the barrier
       if (team == 0) {
         if (valid) {
-          const int type = PAIR(S[i], S[j]);
+          const int type = OWN(i, j);
           const int si1 = S[i + 1], sj1 = S[j - 1];
           if (d < SFD_TURN + 3) {  // first cell of this centre
 #pragma unroll
@@ -247,7 +250,7 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
         }
       } else if (team == 1) {
         if (valid) {
-          const int type = PAIR(S[i], S[j]);
+          const int type = OWN(i, j);
           const int sp = S[i + 1];  // row of the u1 = 0 bulge candidates
           const double *dB1 = DERP(2, j - 1) + i + 1;
           const double *qbA = QB + i;  // row i+1
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
       } else if (team == 2) {
         if (qvalid) qm_half = qm_part(1);
         if (valid) {
-          const int type = PAIR(S[i], S[j]);
+          const int type = OWN(i, j);
           const int si1 = S[i + 1], sj1 = S[j - 1];
           const double *d1N2 = DERP(1, j - 2) + i;
           const double *f1N = FAC + 625 + SF_PK_CODE(BWD[i + 2]);
@@ -281,7 +284,7 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
         }
       } else {
         if (valid) {
-          const int type = PAIR(S[i], S[j]);
+          const int type = OWN(i, j);
           const int si1 = S[i + 1], sj1 = S[j - 1];
           // sum_a qm[i+1,i+a-1] qm1[i+a,j-1], a = 6..d-5; eight terms per trip, the overshoot reads rows of
           // qm1 that are still 0 (rows > j-5 of column j-1)
@@ -307,7 +310,7 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
       __syncthreads();
       if (team == 2 && qvalid) QMD(dq, i) = qm_half + ZP[4 * VW + i];
       if (team == 2 && valid) {
-        const int type = PAIR(S[i], S[j]);
+        const int type = OWN(i, j);
         const int tr = sfd_rtype(type);
         const int sp1 = S[i - 1], sq1 = S[j + 1];
         const double qbij = type ? (ZP[i] + ZP[VW + i]) + (ZP[2 * VW + i] + ZP[3 * VW + i]) : 0.0;
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
       double val = 0.0;
       const int i = tid + 1;
       if (i + SFD_TURN + 1 <= j) {
-        const int type = PAIR(S[i], S[j]);
+        const int type = OWN(i, j);
         if (type) val = q5[i - 1] * QBC(i, j) * sfx_extloop(X, type, i > 1 ? S[i - 1] : -1, j < W ? S[j + 1] : -1);
       }
       val = sf_block_sum(val, red);
@@ -340,7 +343,7 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
       double val = 0.0;
       const int j = tid + 1;
       if (j <= W && i + SFD_TURN + 1 <= j) {
-        const int type = PAIR(S[i], S[j]);
+        const int type = OWN(i, j);
         if (type) val = QBC(i, j) * sfx_extloop(X, type, i > 1 ? S[i - 1] : -1, j < W ? S[j + 1] : -1) * q3[j + 1];
       }
       val = sf_block_sum(val, red);
@@ -421,7 +424,7 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
             }
             H[0] = c3 ? dI3[-3] * WN[0] : 0.0;
           }
-          const int type = PAIR(S[k], S[l]);
+          const int type = OWN(k, l);
           // exterior term, then the small special loops with (k,l) as the INNER pair — branch-free as in the
           // inside pass: rows / columns clamped to existing ones, enclosing pairs that do not exist dropped by
           // a select, all weights fetched up front
@@ -466,7 +469,7 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
         }
       } else if (team == 1) {
         if (valid) {
-          const int type = PAIR(S[k], S[l]);
+          const int type = OWN(k, l);
           const int sp1 = S[k - 1];
           const double *dB1 = DERP(2, l + 1) + k - 1;
           const double *qbA = QB + (k > 1 ? k - 2 : 0);  // row k-1 (row 1 for speculative reads)
@@ -484,7 +487,7 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
       } else if (team == 2) {
         if (valid) {
           r1_half = r1_part(1);
-          const int type = PAIR(S[k], S[l]);
+          const int type = OWN(k, l);
           const int rt = sfd_rtype(type);
           const int sp1 = S[k - 1], sq1 = S[l + 1];
           const double *d1N2 = DERP(1, l + 2) + k;
@@ -505,7 +508,7 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
         }
       } else {
         if (valid) {
-          const int type = PAIR(S[k], S[l]);
+          const int type = OWN(k, l);
           const int sp1 = S[k - 1], sq1 = S[l + 1];
           // (k,l) as a stem of a multiloop closed by (i,m), i < k, m > l
           double ms = 0.0, ms2 = 0.0;
@@ -532,7 +535,7 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
       }
       __syncthreads();
       if (team == 2 && valid) {
-        const int type = PAIR(S[k], S[l]);
+        const int type = OWN(k, l);
         const int si1 = S[k + 1], sj1 = S[l - 1];
         const double qbkl = QBC(k, l);
         double o = 0.0;
@@ -571,6 +574,7 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
 #undef QMD
 #undef DERP
 #undef PAIR
+#undef OWN
 }
 
 static inline hipError_t sf_pfl_configure() {

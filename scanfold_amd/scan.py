@@ -147,6 +147,7 @@ def build_parser():
     parser.add_argument('--print_random', type=str, default='off', help='print to screen option (default off)')
     parser.add_argument('-c', '--constraints', type=str, help='optional | input constraint file')
     # additions
+    parser.add_argument('--span', type=int, default=0, help='maximum base-pair span (ScanFold.py --span); 0 = none')
     parser.add_argument('--seed', type=int, default=0, help='seed of the device shuffle generator')
     parser.add_argument('--shuffle-backend', choices=("device", "python"), default="device")
     parser.add_argument('--params', type=str, default=None, help='ViennaRNA .par (v2.0) file to use')
@@ -165,6 +166,7 @@ def main(argv=None):
     out_path = args.output or (args.filename + ".forward.win_" + str(window_size) + ".stp_" + str(step_size)
                                + ".rnd_" + str(randomizations) + ".shfl_" + str(shuffle_type) + ".txt")
     eng = _lib.get_engine()
+    eng.set_max_bp_span(args.span)
     if args.params:
         from . import params as _params
         eng.load_params(_params.load_par(args.params))

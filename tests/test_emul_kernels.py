@@ -136,3 +136,32 @@ def test_bad_arguments_return_status(emul):
     with pytest.raises(ScanFoldHipError):
         emul.scan("ACGU" * 10, 30, 1, 0, 2, 2, 7, 0)  # unknown shuffle kind
     assert len(emul.mfe_batch(np.zeros((0, 30), dtype=np.uint8))) == 0
+
+
+def test_max_bp_span_every_kernel(emul, oracle):
+    """sf_set_max_bp_span: MFE (every kernel mode), traceback and partition function follow the oracle."""
+    emul.load_params(params.default_params())
+    rng = np.random.default_rng(5)
+    try:
+        for W, span in ((40, 12), (70, 30), (120, 50), (140, 45)):  # 140: the device-table PF kernel
+            arr = random_seqs(rng, 3, W)
+            oracle.set_max_bp_span(span)
+            emul.set_max_bp_span(span)
+            ref = oracle.mfe_batch(arr)
+            unlimited = None
+            for mode in (0, 1, 2, 3):
+                emul.set_kernel_mode(mode)
+                assert (emul.mfe_batch(arr) == ref).all(), (W, span, mode)
+            emul.set_kernel_mode(0)
+            e, db = emul.mfe_trace_batch(arr)
+            r = emul.pf_batch(arr)
+            for k in range(len(arr)):
+                s = bytes(arr[k]).decode()
+                assert (db[k], e[k]) == oracle.mfe(s)
+                o = oracle.pf(s)
+                assert o["centroid"] == r["centroid"][k] and abs(o["dG"] - r["dG"][k]) < 1e-9
+                assert abs(o["mean_bp_dist"] - r["mean_bp_dist"][k]) < 1e-9
+    finally:
+        emul.set_kernel_mode(0)
+        emul.set_max_bp_span(0)
+        oracle.set_max_bp_span(0)

@@ -329,3 +329,38 @@ def test_cli_writes_the_reference_named_file(gpu_engine, tmp_path):
     assert len(lines) == 1 + 8 + 1 and lines[1].split("\t")[:3] == ["1", "120", "37"]
     f = lines[1].split("\t")
     assert len(f) == 10 and len(f[7]) == len(f[8]) == len(f[9]) == 120
+
+
+@pytest.mark.gpu
+def test_max_bp_span_matches_oracle(gpu_engine, oracle):
+    """sf_set_max_bp_span (RNA.md().max_bp_span, ScanFold.py:214-215): every MFE kernel, traceback and PF."""
+    rng = np.random.default_rng(99)
+    try:
+        for W, span, n in ((120, 40, 600), (100, 100, 300), (200, 70, 120), (300, 90, 8)):
+            arr = random_seqs(rng, n, W)
+            oracle.set_max_bp_span(span)
+            gpu_engine.set_max_bp_span(span)
+            ref = oracle.mfe_batch(arr)
+            for mode in (0, 1, 2, 3):
+                gpu_engine.set_kernel_mode(mode)
+                got = gpu_engine.mfe_batch(arr[: (64 if mode == 1 else n)])
+                assert (got == ref[: len(got)]).all(), (W, span, mode)
+            gpu_engine.set_kernel_mode(0)
+            m = min(n, 40)
+            e, db = gpu_engine.mfe_trace_batch(arr[:m])
+            r = gpu_engine.pf_batch(arr[:m])
+            for k in range(m):
+                s = bytes(arr[k]).decode()
+                assert (db[k], e[k]) == oracle.mfe(s)
+                o = oracle.pf(s)
+                assert o["centroid"] == r["centroid"][k] and abs(o["dG"] - r["dG"][k]) < PF_TOL
+                assert abs(o["mean_bp_dist"] - r["mean_bp_dist"][k]) < PF_TOL
+        # a span >= W changes nothing
+        arr = random_seqs(rng, 256, 120)
+        oracle.set_max_bp_span(0)
+        gpu_engine.set_max_bp_span(120)
+        assert (gpu_engine.mfe_batch(arr) == oracle.mfe_batch(arr)).all()
+    finally:
+        gpu_engine.set_kernel_mode(0)
+        gpu_engine.set_max_bp_span(0)
+        oracle.set_max_bp_span(0)

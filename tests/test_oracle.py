@@ -109,3 +109,29 @@ def test_known_small_answers(oracle):
     db, e = oracle.mfe("GGGGCUUCGGCCCC")
     assert db == "(((((....)))))" or db.count("(") >= 4
     assert oracle.eval_structure("GGGGCUUCGGCCCC", db) == e
+
+
+def test_max_bp_span_dp_equals_enumeration(oracle):
+    """RNA.md().max_bp_span (ScanFold.py:214-215): with the limit set, the DP, the exhaustive enumeration and the
+    partition function agree again (the enumeration only builds structures whose pairs respect the span)."""
+    import numpy as np
+    rng = np.random.default_rng(77)
+    try:
+        for span in (6, 9, 12):
+            oracle.set_max_bp_span(span)
+            for _ in range(6):
+                s = "".join("ACGU"[k] for k in rng.integers(0, 4, 15))
+                e, Z, bpp, cnt = oracle.brute(s, want_bpp=True)
+                db, e_dp = oracle.mfe(s)
+                assert e_dp == e and oracle.eval_structure(s, db) == e
+                stack = []
+                for k, ch in enumerate(db):
+                    if ch == "(":
+                        stack.append(k)
+                    elif ch == ")":
+                        assert k - stack.pop() + 1 <= span
+                r = oracle.pf(s, want_bpp=True)
+                assert abs(np.exp(-r["dG"] * 1000.0 / (1.98717 * 310.15)) - Z) <= 1e-9 * Z
+                assert np.abs(r["bpp"] - bpp).max() < 1e-9
+    finally:
+        oracle.set_max_bp_span(0)

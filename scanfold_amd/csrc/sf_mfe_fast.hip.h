@@ -45,6 +45,9 @@
 #ifndef SF_EXT_TABLE
 #define SF_EXT_TABLE 0
 #endif
+#ifndef SF_FAST_SPLIT
+#define SF_FAST_SPLIT 1  // long diagonals: the idle second wave of a group takes part of the cell's work
+#endif
 #define SF_INF16 30000
 #define SF_FAST_THRESH 10000
 #define SF_FAST_OVF (-12000)
@@ -178,10 +181,18 @@ struct SfFastCtx {
 // enclosed cell (i+1, j-1) on entry, of (i, j) on exit.  slot2 = (d-2) mod NR, slotd = d mod NR.
 // G ("guarded"): d < 36, the loop-size limit d-6 is below MAXLOOP and every size is tested against it;
 // !G: all sizes 0..30 exist, the candidate code is one straight-line block the scheduler can pipeline.
-template <bool G, int WT>
+// SEC: which sections of the cell this call runs.  Normally all of them, in this order; on the long diagonals,
+// where the cells of a wave group fit one wave and the group's other wave would idle, the kernel gives
+// SF_SEC_HELP to that wave and SF_SEC_P1 | SF_SEC_DML, then (after a barrier) SF_SEC_FIN to the first (see the kernel).
+//   SF_SEC_P1    generic-loop recurrence (updates HP)
+//   SF_SEC_HELP  special loops + bulge / 1xn minima -> eh (the minimum over those candidates of a pairable cell)
+//   SF_SEC_DML   multiloop split -> dec
+//   SF_SEC_FIN   hairpin, generic minima, c = min(..., eh), multiloop closing; publishes the cell (needs dec)
+enum { SF_SEC_P1 = 1, SF_SEC_HELP = 2, SF_SEC_DML = 4, SF_SEC_FIN = 8, SF_SEC_ALL = 15 };
+template <bool G, int WT, int SEC>
 __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, const int i, const bool valid,
                                              const int slot2, const int slotd, uint32_t (&HP)[14], int &ovf,
-                                             const bool final_fml, const int fnb, int &fpart) {
+                                             const bool final_fml, const int fnb, int &fpart, int &dec, int &eh) {
 // H[x] (x = size - 4) lives in the int16 halves of HP[x/2]: 14 registers instead of 27 under the 128-VGPR cap
 #define HGET(x) (((x)&1) ? ((int)HP[(x) >> 1] >> 16) : (int)(int16_t)(HP[(x) >> 1] & 0xffffu))
 #define HSET(x, v)                                                                                       \
@@ -199,6 +210,7 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
 // row of diagonal d-2-u in the rolling tables
 #define ROW(u) ((slot2 - (u) < 0 ? slot2 - (u) + SF_FAST_NR : slot2 - (u)) * RW)
 
+  if (SEC & SF_SEC_P1) {
   // ---- pass 1 (every cell): per-size minima of the generic interior candidates ----
 #ifndef SF_ABL_PASS1
   if (G) {
@@ -245,56 +257,55 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
   if (!G || umax >= 4) HSET(0, X.CI[ROW(4) + i0 + 3] + SF_UNI(X.uNIN, 0));
 #endif
 
-  // ---- pass 2 (pairable cells): c[i,j] ----
-  int c = SF_INF16;
-  if (type) {
-    const int TAU = X.TAU;
-    const sf_params_blob &P = X.D->P;
-    int e;
-    if (G && d <= 7) e = sfd_hairpin(X.D, S, i, j, type);  // sizes 3, 4, 6 may be special loops
-    else e = X.D->hp_init[d - 1] + X.tH[SF_TIDX(type, si1, sj1)];
-    if (!G || umax >= 0) {
+  }
+
+  // ---- special loops, bulges, 1 x n loops (pairable cells): eh ----
+  if (SEC & SF_SEC_HELP) {
+    eh = SF_FAST_BIG;
+    if (type && (!G || umax >= 0)) {
+      const int TAU = X.TAU;
+      const sf_params_blob &P = X.D->P;
       const int tau_out = type > 2 ? TAU : 0;
       const int16_t *st = X.tStack + type * 8;
 #ifndef SF_ABL_RARE
       {  // stack
         const int t2r = sfd_rtype(X.tPair[si1 * 8 + sj1]);
-        e = sfd_min(e, X.CB[ROW(0) + i0 + 1] - (t2r > 2 ? TAU : 0) + st[t2r]);
+        eh = sfd_min(eh, X.CB[ROW(0) + i0 + 1] - (t2r > 2 ? TAU : 0) + st[t2r]);
       }
       if (!G || umax >= 1) {  // one-nucleotide bulges keep the stack
         const int b1 = SF_UNI(X.uBUL, 1);
         const int16_t *row = X.CB + ROW(1) + i0;
         const int ta = sfd_rtype(X.tPair[si1 * 8 + S[j - 2]]);  // (i+1, j-2)
-        e = sfd_min(e, row[1] - (ta > 2 ? TAU : 0) + b1 + st[ta]);
+        eh = sfd_min(eh, row[1] - (ta > 2 ? TAU : 0) + b1 + st[ta]);
         const int tb = sfd_rtype(X.tPair[S[i + 2] * 8 + sj1]);  // (i+2, j-1)
-        e = sfd_min(e, row[2] - (tb > 2 ? TAU : 0) + b1 + st[tb]);
+        eh = sfd_min(eh, row[2] - (tb > 2 ? TAU : 0) + b1 + st[tb]);
       }
       if (!G || umax >= 2) {  // 1 x 1: (i+2, j-2)
         const int t2r = sfd_rtype(X.tPair[S[i + 2] * 8 + S[j - 2]]);
-        e = sfd_min(e, X.CB[ROW(2) + i0 + 2] - (t2r > 2 ? TAU : 0) + P.int11[type][t2r][si1][sj1]);
+        eh = sfd_min(eh, X.CB[ROW(2) + i0 + 2] - (t2r > 2 ? TAU : 0) + P.int11[type][t2r][si1][sj1]);
       }
       if (!G || umax >= 3) {  // 1 x 2 and 2 x 1
         const int16_t *row = X.CB + ROW(3) + i0;
         const int ta = sfd_rtype(X.tPair[S[i + 2] * 8 + S[j - 3]]);  // (i+2, j-3), sq1 = S[j-2]
-        e = sfd_min(e, row[2] - (ta > 2 ? TAU : 0) + P.int21[type][ta][si1][S[j - 2]][sj1]);
+        eh = sfd_min(eh, row[2] - (ta > 2 ? TAU : 0) + P.int21[type][ta][si1][S[j - 2]][sj1]);
         const int tb = sfd_rtype(X.tPair[S[i + 3] * 8 + S[j - 2]]);  // (i+3, j-2), sp1 = S[i+2]
-        e = sfd_min(e, row[3] - (tb > 2 ? TAU : 0) + P.int21[tb][type][sj1][si1][S[i + 2]]);
+        eh = sfd_min(eh, row[3] - (tb > 2 ? TAU : 0) + P.int21[tb][type][sj1][si1][S[i + 2]]);
       }
       if (!G || umax >= 4) {  // 2 x 2: (i+3, j-3)
         const int t2r = sfd_rtype(X.tPair[S[i + 3] * 8 + S[j - 3]]);
-        e = sfd_min(e, X.CB[ROW(4) + i0 + 3] - (t2r > 2 ? TAU : 0) + P.int22[type][t2r][si1][S[i + 2]][S[j - 2]][sj1]);
+        eh = sfd_min(eh, X.CB[ROW(4) + i0 + 3] - (t2r > 2 ? TAU : 0) + P.int22[type][t2r][si1][S[i + 2]][S[j - 2]][sj1]);
       }
       if (!G || umax >= 5) {  // 2 x 3 and 3 x 2
         const int16_t *row = X.CB + ROW(5) + i0;
         const int m23 = X.t23[SF_TIDX(type, si1, sj1)] + X.F->L23;
         const int ta = sfd_rtype(X.tPair[S[i + 3] * 8 + S[j - 4]]);  // (i+3, j-4); sp1 = S[i+2], sq1 = S[j-3]
-        e = sfd_min(e, row[3] - (ta > 2 ? TAU : 0) + m23 + X.t23[SF_TIDX(ta, S[j - 3], S[i + 2])]);
+        eh = sfd_min(eh, row[3] - (ta > 2 ? TAU : 0) + m23 + X.t23[SF_TIDX(ta, S[j - 3], S[i + 2])]);
         const int tb = sfd_rtype(X.tPair[S[i + 4] * 8 + S[j - 3]]);  // (i+4, j-3); sp1 = S[i+3], sq1 = S[j-2]
-        e = sfd_min(e, row[4] - (tb > 2 ? TAU : 0) + m23 + X.t23[SF_TIDX(tb, S[j - 2], S[i + 3])]);
+        eh = sfd_min(eh, row[4] - (tb > 2 ? TAU : 0) + m23 + X.t23[SF_TIDX(tb, S[j - 2], S[i + 3])]);
       }
 #endif
-      // bulges (size u >= 2), 1 x n loops (total size u >= 4) and the generic minima, one rolling row per u
-      int gb = SF_FAST_BIG, g1 = SF_FAST_BIG, gg = SF_FAST_BIG;
+      // bulges (size u >= 2) and 1 x n loops (total size u >= 4), one rolling row per u
+      int gb = SF_FAST_BIG, g1 = SF_FAST_BIG;
 #ifndef SF_ABL_PASS2
       if (G) {
 #pragma unroll
@@ -303,11 +314,10 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
             const int rw = ROW(u) + i0;
             gb = sfd_min(gb, sfd_min(X.CB[rw + 1], X.CB[rw + 1 + u]) + SF_UNI(X.uBUL, u));
             if (u >= 4) g1 = sfd_min(g1, sfd_min(X.C1N[rw + 2], X.C1N[rw + u]) + SF_UNI(X.uL1N, u - 1));
-            if (u >= 6) gg = sfd_min(gg, HGET(u - 4) + SF_UNI(X.uIL, u));
           }
         }
       } else {
-        // batches of two sizes = 14 LDS reads in flight
+        // batches of two sizes = 12 LDS reads in flight
 #pragma unroll
         for (int ub = 2; ub <= 30; ub += 2) {
           int b1[2], b2[2], n1[2], n2[2], tb[2], tn[2];
@@ -329,54 +339,16 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
             }
           }
         }
-        {
-          // generic minima plus loop initiation, two sizes per packed add / min (size 31 does not exist: its
-          // half of HP[13] stays INF)
-          uint32_t ggp = sf_pk(32767, 32767);
-#pragma unroll
-          for (int pp = 1; pp <= 13; pp++) ggp = sf_pkmin(ggp, sf_pkadd(HP[pp], sf_ldw(X.uIL + 2 * pp + 4)));
-          gg = sfd_min(sf_lo(ggp), sf_hi(ggp));
-        }
       }
 #endif
-      e = sfd_min(e, gb + tau_out);
-      e = sfd_min(e, g1 + X.t1n[SF_TIDX(type, si1, sj1)]);
-      e = sfd_min(e, gg + X.tI[SF_TIDX(type, si1, sj1)]);
+      eh = sfd_min(eh, gb + tau_out);
+      eh = sfd_min(eh, g1 + X.t1n[SF_TIDX(type, si1, sj1)]);
     }
-    // multiloop closed by (i,j)
-    {
-      const int tr = sfd_rtype(type);
-      const int dml = X.DMLr[((d - 2) & 3) * RW + i0 + 1];
-      e = sfd_min(e, dml + X.tM[SF_TIDX(tr, sj1, si1)] + (tr > 2 ? TAU : 0) + X.MLintern + X.MLclosing);
-    }
-    c = e;
-    if (c < SF_FAST_OVF) ovf = 1;
   }
 
-  // ---- publish the cell ----
-  const int rbd = slotd * RW + i0;
-  int f = SF_FAST_BIG;
-  if (type) {
-    const int tr = sfd_rtype(type);
-    const int sp1 = S[i - 1], sq1 = S[j + 1];
-    const int tau_in = tr > 2 ? X.TAU : 0;
-    X.CI[rbd] = (int16_t)(c + X.tI[SF_TIDX(tr, sq1, sp1)]);
-    X.C1N[rbd] = (int16_t)(c + X.t1n[SF_TIDX(tr, sq1, sp1)]);
-    X.CB[rbd] = (int16_t)(c + tau_in);
-    int stem;  // E_MLstem(type, S[i-1], S[j+1]); sequence ends have dangles only
-    if (i > 1 && j < W) stem = X.tM[SF_TIDX(type, sp1, sq1)];
-    else if (i > 1) stem = X.tD5[type * 5 + sp1];
-    else if (j < W) stem = X.tD3[type * 5 + sq1];
-    else stem = 0;
-    f = c + stem + tau_in + X.MLintern;
-  } else {
-    X.CI[rbd] = SF_INF16; X.C1N[rbd] = SF_INF16; X.CB[rbd] = SF_INF16;
-  }
-  X.cg[SF_CGIDX(i, j)] = (int16_t)c;  // row i, column j: the exterior pass reads rows coalesced
-  // fML[i,j]: the two neighbours on diagonal d-1 are final only for the even-diagonal group, which gets their
-  // minimum (+MLbase) in fnb from its own fix-up of the previous step (see the kernel)
-  if (final_fml && d > SFD_TURN + 1) f = sfd_min(f, fnb);
-  int dec = SF_FAST_BIG;
+  // ---- multiloop split ----
+  if (SEC & SF_SEC_DML) {
+    dec = SF_FAST_BIG;
 #ifndef SF_ABL_DML
   {
     // fML[i, i+m] = fML_tri[FBASE(m) + i0], fML[i+m+1, j] = fML_tri[FBASE(d-m-1) + i0+m+1]; both offsets are
@@ -411,6 +383,69 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
     dec = sfd_min(dec, dec2);
   }
 #endif
+  }
+
+  if (!(SEC & SF_SEC_FIN)) return;
+  // ---- c[i,j] of a pairable cell ----
+  int c = SF_INF16;
+  if (type) {
+    const int TAU = X.TAU;
+    int e;
+    if (G && d <= 7) e = sfd_hairpin(X.D, S, i, j, type);  // sizes 3, 4, 6 may be special loops
+    else e = X.D->hp_init[d - 1] + X.tH[SF_TIDX(type, si1, sj1)];
+    if (!G || umax >= 0) {
+      int gg = SF_FAST_BIG;
+#ifndef SF_ABL_PASS2
+      if (G) {
+#pragma unroll
+        for (int u = 6; u <= 30; ++u)
+          if (u <= umax) gg = sfd_min(gg, HGET(u - 4) + SF_UNI(X.uIL, u));
+      } else {
+        // generic minima plus loop initiation, two sizes per packed add / min (size 31 does not exist: its
+        // half of HP[13] stays INF)
+        uint32_t ggp = sf_pk(32767, 32767);
+#pragma unroll
+        for (int pp = 1; pp <= 13; pp++) ggp = sf_pkmin(ggp, sf_pkadd(HP[pp], sf_ldw(X.uIL + 2 * pp + 4)));
+        gg = sfd_min(sf_lo(ggp), sf_hi(ggp));
+      }
+#endif
+      e = sfd_min(e, eh);
+      e = sfd_min(e, gg + X.tI[SF_TIDX(type, si1, sj1)]);
+    }
+    // multiloop closed by (i,j)
+    {
+      const int tr = sfd_rtype(type);
+      const int dml = X.DMLr[((d - 2) & 3) * RW + i0 + 1];
+      e = sfd_min(e, dml + X.tM[SF_TIDX(tr, sj1, si1)] + (tr > 2 ? TAU : 0) + X.MLintern + X.MLclosing);
+    }
+    c = e;
+    if (c < SF_FAST_OVF) ovf = 1;
+  }
+
+  // ---- publish the cell ----
+  // ---- publish the cell ----
+  const int rbd = slotd * RW + i0;
+  int f = SF_FAST_BIG;
+  if (type) {
+    const int tr = sfd_rtype(type);
+    const int sp1 = S[i - 1], sq1 = S[j + 1];
+    const int tau_in = tr > 2 ? X.TAU : 0;
+    X.CI[rbd] = (int16_t)(c + X.tI[SF_TIDX(tr, sq1, sp1)]);
+    X.C1N[rbd] = (int16_t)(c + X.t1n[SF_TIDX(tr, sq1, sp1)]);
+    X.CB[rbd] = (int16_t)(c + tau_in);
+    int stem;  // E_MLstem(type, S[i-1], S[j+1]); sequence ends have dangles only
+    if (i > 1 && j < W) stem = X.tM[SF_TIDX(type, sp1, sq1)];
+    else if (i > 1) stem = X.tD5[type * 5 + sp1];
+    else if (j < W) stem = X.tD3[type * 5 + sq1];
+    else stem = 0;
+    f = c + stem + tau_in + X.MLintern;
+  } else {
+    X.CI[rbd] = SF_INF16; X.C1N[rbd] = SF_INF16; X.CB[rbd] = SF_INF16;
+  }
+  X.cg[SF_CGIDX(i, j)] = (int16_t)c;  // row i, column j: the exterior pass reads rows coalesced
+  // fML[i,j]: the two neighbours on diagonal d-1 are final only for the even-diagonal group, which gets their
+  // minimum (+MLbase) in fnb from its own fix-up of the previous step (see the kernel)
+  if (final_fml && d > SFD_TURN + 1) f = sfd_min(f, fnb);
   f = sfd_min(f, dec);
   X.DMLr[(d & 3) * RW + i0] = (int16_t)(dec > SF_FAST_THRESH ? SF_INF16 : dec);
   fpart = f;
@@ -804,6 +839,8 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
   const int tg = tid - grp * NG;
   const int OFF = (NG > 64) ? (((W + 1) >> 1) - 32 + NG) & (NG - 1) : 0;
   const int v = (tg + OFF) & (NG - 1);
+  // first even diagonal from which the cells of both groups lie in the lanes tg < 64 (W >= 64: OFF >= 0, no wrap)
+  const int split_d0 = (NG == 128 && W >= 64 && SF_FAST_SPLIT) ? ((sfd_max(sfd_max(SFD_MAXLOOP + 6, 2 * (OFF - 1)), 2 * (W - OFF - 63)) + 1) & ~1) : 1 << 30;
 
   for (int seq = blockIdx.x; seq < n; seq += gridDim.x) {
     const uint8_t *src = seqs + (size_t)seq * W;
@@ -822,9 +859,17 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
     int slot2 = (SFD_TURN + 1 + grp - 2) % SF_FAST_NR, slotd = (SFD_TURN + 1 + grp) % SF_FAST_NR;
     for (int d0 = SFD_TURN + 1; d0 < W; d0 += 2) {
       const int d = d0 + grp;
-      const int i = v - (d >> 1);
+      // Long diagonals (d0 >= split_d0): the cells of a group fit its first wave, so the second wave — which would
+      // idle — mirrors it (same lane -> same cell) and takes the special loops and the bulge / 1xn minima of
+      // those cells, while the first does the generic-loop recurrence and the multiloop split; the partial
+      // result crosses in LDS (in the C1N entry the cell will publish, unread until the next step) at a barrier,
+      // then the first wave finishes the cell.  The dependent chain of such a step is ~45 % shorter.
+      const bool split = (NG == 128) && d0 >= split_d0;
+      const bool helper = split && tg >= 64;
+      const int i = (helper ? ((v - 64) & (NG - 1)) : v) - (d >> 1);
       const bool valid = (d < W) && (i >= 1) && (i + d <= W);
       int fpart = SF_FAST_BIG;
+      int dec = SF_FAST_BIG, eh = SF_FAST_BIG;
 #ifdef SF_STAMP
       const unsigned long long t0 = SF_T();
 #endif
@@ -833,8 +878,20 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
 #else
       if (__ballot(valid)) {
 #endif
-        if (d0 < SFD_MAXLOOP + 6) sf_fast_cell<true, WT>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart);
-        else sf_fast_cell<false, WT>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart);
+        if (d0 < SFD_MAXLOOP + 6) sf_fast_cell<true, WT, SF_SEC_ALL>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh);
+        else if (!split) sf_fast_cell<false, WT, SF_SEC_ALL>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh);
+        else if (!helper) sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_DML>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh);
+        else {
+          sf_fast_cell<false, WT, SF_SEC_HELP>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh);
+          if (valid) X.C1N[slotd * (W - 4) + i - 1] = (int16_t)sfd_min(eh, 32000);
+        }
+      }
+      if (split) {
+        __syncthreads();
+        if (!helper && __ballot(valid)) {
+          if (valid) eh = X.C1N[slotd * (W - 4) + i - 1];
+          sf_fast_cell<false, WT, SF_SEC_FIN>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh);
+        }
       }
 #ifdef SF_STAMP
       const unsigned long long t1 = SF_T();
@@ -848,7 +905,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
       // group's next cell (i-1, j+1), which needs the cells i-1 and i of it — so every even lane finishes BOTH
       // (storing only its own, i) and keeps their minimum in a register.  No second barrier: nothing else reads
       // these entries before several later barriers (the multiloop split of d reads spans <= d-5).
-      if (grp == 0 && valid) {
+      if (grp == 0 && valid && !helper) {
         const int d1 = d0 + 1;
         const int fbd = FBASE(d1), fbe = FBASE(d0);
         int g[2];

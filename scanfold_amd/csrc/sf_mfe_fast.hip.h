@@ -346,8 +346,9 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
     }
   }
 
-  // ---- multiloop split ----
-  if (SEC & SF_SEC_DML) {
+  // ---- multiloop split: before the barrier when the cell is finished by a later call, else after publishing c
+  // (fewer values live across it) ----
+  auto multiloop_split = [&]() {
     dec = SF_FAST_BIG;
 #ifndef SF_ABL_DML
   {
@@ -383,7 +384,8 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
     dec = sfd_min(dec, dec2);
   }
 #endif
-  }
+    };
+  if ((SEC & SF_SEC_DML) && !(SEC & SF_SEC_FIN)) multiloop_split();
 
   if (!(SEC & SF_SEC_FIN)) return;
   // ---- c[i,j] of a pairable cell ----
@@ -446,6 +448,7 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
   // fML[i,j]: the two neighbours on diagonal d-1 are final only for the even-diagonal group, which gets their
   // minimum (+MLbase) in fnb from its own fix-up of the previous step (see the kernel)
   if (final_fml && d > SFD_TURN + 1) f = sfd_min(f, fnb);
+  if ((SEC & SF_SEC_DML) && (SEC & SF_SEC_FIN)) multiloop_split();
   f = sfd_min(f, dec);
   X.DMLr[(d & 3) * RW + i0] = (int16_t)(dec > SF_FAST_THRESH ? SF_INF16 : dec);
   fpart = f;

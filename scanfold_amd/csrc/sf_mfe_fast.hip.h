@@ -187,12 +187,13 @@ struct SfFastCtx {
 //   SF_SEC_P1    generic-loop recurrence (updates HP)
 //   SF_SEC_HELP  special loops + bulge / 1xn minima -> eh (the minimum over those candidates of a pairable cell)
 //   SF_SEC_DML   multiloop split -> dec
-//   SF_SEC_FIN   hairpin, generic minima, c = min(..., eh), multiloop closing; publishes the cell (needs dec)
-enum { SF_SEC_P1 = 1, SF_SEC_HELP = 2, SF_SEC_DML = 4, SF_SEC_FIN = 8, SF_SEC_ALL = 15 };
+//   SF_SEC_C0    hairpin and generic minima -> e0 (needs HP)
+//   SF_SEC_FIN   c = min(e0, eh, multiloop closing); publishes the cell (needs dec)
+enum { SF_SEC_P1 = 1, SF_SEC_HELP = 2, SF_SEC_DML = 4, SF_SEC_FIN = 8, SF_SEC_C0 = 16, SF_SEC_ALL = 31 };
 template <bool G, int WT, int SEC>
 __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, const int i, const bool valid,
                                              const int slot2, const int slotd, uint32_t (&HP)[14], int &ovf,
-                                             const bool final_fml, const int fnb, int &fpart, int &dec, int &eh) {
+                                             const bool final_fml, const int fnb, int &fpart, int &dec, int &eh, int &e0) {
 // H[x] (x = size - 4) lives in the int16 halves of HP[x/2]: 14 registers instead of 27 under the 128-VGPR cap
 #define HGET(x) (((x)&1) ? ((int)HP[(x) >> 1] >> 16) : (int)(int16_t)(HP[(x) >> 1] & 0xffffu))
 #define HSET(x, v)                                                                                       \
@@ -385,42 +386,49 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
   }
 #endif
     };
+
+  // ---- hairpin, generic minima, multiloop closing (pairable cells): e0 ----
+  if (SEC & SF_SEC_C0) {
+    e0 = SF_FAST_BIG;
+    if (type) {
+      const int TAU = X.TAU;
+      int e;
+      if (G && d <= 7) e = sfd_hairpin(X.D, S, i, j, type);  // sizes 3, 4, 6 may be special loops
+      else e = X.D->hp_init[d - 1] + X.tH[SF_TIDX(type, si1, sj1)];
+      if (!G || umax >= 0) {
+        int gg = SF_FAST_BIG;
+#ifndef SF_ABL_PASS2
+        if (G) {
+#pragma unroll
+          for (int u = 6; u <= 30; ++u)
+            if (u <= umax) gg = sfd_min(gg, HGET(u - 4) + SF_UNI(X.uIL, u));
+        } else {
+          // generic minima plus loop initiation, two sizes per packed add / min (size 31 does not exist: its
+          // half of HP[13] stays INF)
+          uint32_t ggp = sf_pk(32767, 32767);
+#pragma unroll
+          for (int pp = 1; pp <= 13; pp++) ggp = sf_pkmin(ggp, sf_pkadd(HP[pp], sf_ldw(X.uIL + 2 * pp + 4)));
+          gg = sfd_min(sf_lo(ggp), sf_hi(ggp));
+        }
+#endif
+        e = sfd_min(e, gg + X.tI[SF_TIDX(type, si1, sj1)]);
+      }
+      // multiloop closed by (i,j)
+      {
+        const int tr = sfd_rtype(type);
+        const int dml = X.DMLr[((d - 2) & 3) * RW + i0 + 1];
+        e = sfd_min(e, dml + X.tM[SF_TIDX(tr, sj1, si1)] + (tr > 2 ? TAU : 0) + X.MLintern + X.MLclosing);
+      }
+      e0 = e;
+    }
+  }
   if ((SEC & SF_SEC_DML) && !(SEC & SF_SEC_FIN)) multiloop_split();
 
   if (!(SEC & SF_SEC_FIN)) return;
   // ---- c[i,j] of a pairable cell ----
   int c = SF_INF16;
   if (type) {
-    const int TAU = X.TAU;
-    int e;
-    if (G && d <= 7) e = sfd_hairpin(X.D, S, i, j, type);  // sizes 3, 4, 6 may be special loops
-    else e = X.D->hp_init[d - 1] + X.tH[SF_TIDX(type, si1, sj1)];
-    if (!G || umax >= 0) {
-      int gg = SF_FAST_BIG;
-#ifndef SF_ABL_PASS2
-      if (G) {
-#pragma unroll
-        for (int u = 6; u <= 30; ++u)
-          if (u <= umax) gg = sfd_min(gg, HGET(u - 4) + SF_UNI(X.uIL, u));
-      } else {
-        // generic minima plus loop initiation, two sizes per packed add / min (size 31 does not exist: its
-        // half of HP[13] stays INF)
-        uint32_t ggp = sf_pk(32767, 32767);
-#pragma unroll
-        for (int pp = 1; pp <= 13; pp++) ggp = sf_pkmin(ggp, sf_pkadd(HP[pp], sf_ldw(X.uIL + 2 * pp + 4)));
-        gg = sfd_min(sf_lo(ggp), sf_hi(ggp));
-      }
-#endif
-      e = sfd_min(e, eh);
-      e = sfd_min(e, gg + X.tI[SF_TIDX(type, si1, sj1)]);
-    }
-    // multiloop closed by (i,j)
-    {
-      const int tr = sfd_rtype(type);
-      const int dml = X.DMLr[((d - 2) & 3) * RW + i0 + 1];
-      e = sfd_min(e, dml + X.tM[SF_TIDX(tr, sj1, si1)] + (tr > 2 ? TAU : 0) + X.MLintern + X.MLclosing);
-    }
-    c = e;
+    c = sfd_min(e0, eh);
     if (c < SF_FAST_OVF) ovf = 1;
   }
 
@@ -872,7 +880,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
       const int i = (helper ? ((v - 64) & (NG - 1)) : v) - (d >> 1);
       const bool valid = (d < W) && (i >= 1) && (i + d <= W);
       int fpart = SF_FAST_BIG;
-      int dec = SF_FAST_BIG, eh = SF_FAST_BIG;
+      int dec = SF_FAST_BIG, eh = SF_FAST_BIG, e0 = SF_FAST_BIG;
 #ifdef SF_STAMP
       const unsigned long long t0 = SF_T();
 #endif
@@ -881,11 +889,11 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
 #else
       if (__ballot(valid)) {
 #endif
-        if (d0 < SFD_MAXLOOP + 6) sf_fast_cell<true, WT, SF_SEC_ALL>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh);
-        else if (!split) sf_fast_cell<false, WT, SF_SEC_ALL>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh);
-        else if (!helper) sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_DML>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh);
+        if (d0 < SFD_MAXLOOP + 6) sf_fast_cell<true, WT, SF_SEC_ALL>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0);
+        else if (!split) sf_fast_cell<false, WT, SF_SEC_ALL>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0);
+        else if (!helper) sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_DML>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0);
         else {
-          sf_fast_cell<false, WT, SF_SEC_HELP>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh);
+          sf_fast_cell<false, WT, SF_SEC_HELP>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0);
           if (valid) X.C1N[slotd * (W - 4) + i - 1] = (int16_t)sfd_min(eh, 32000);
         }
       }
@@ -893,7 +901,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
         __syncthreads();
         if (!helper && __ballot(valid)) {
           if (valid) eh = X.C1N[slotd * (W - 4) + i - 1];
-          sf_fast_cell<false, WT, SF_SEC_FIN>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh);
+          sf_fast_cell<false, WT, SF_SEC_FIN>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0);
         }
       }
 #ifdef SF_STAMP

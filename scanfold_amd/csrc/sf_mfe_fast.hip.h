@@ -353,24 +353,26 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
     dec = SF_FAST_BIG;
 #ifndef SF_ABL_DML
   {
-    // fML[i, i+m] = fML_tri[FBASE(m) + i0], fML[i+m+1, j] = fML_tri[FBASE(d-m-1) + i0+m+1]; both offsets are
-    // wave-uniform and advance by simple differences: FBASE(m+1)-FBASE(m) = W-m
-    const int16_t *fa = X.fML + i0;
-    const int16_t *fb2 = X.fML + i0 + 1;
-    int ia = 0;                                             // FBASE(4)
-    int ib = FBASE(d - SFD_TURN - 2) + SFD_TURN + 1;        // FBASE(d-m-1) + m at m = 4
+    // fML[i, i+m] = fML_tri[FBASE(m) + i0], fML[i+m+1, j] = fML_tri[FBASE(d-m-1) + i0+m+1].  Both offsets step by
+    // wave-uniform differences, FBASE(m+1)-FBASE(m) = W-m: inside a batch of eight terms each address is the
+    // previous one plus ONE uniform byte step (a single v_add with a scalar operand), the triangular part
+    // -k(k-1)/2 of the step sequence is a compile-time load offset (pointers rebased by 56 bytes to keep it >= 0).
+    const char *pa = (const char *)(X.fML + i0) - 56;                                              // FBASE(4) = 0
+    const char *pb = (const char *)(X.fML + i0 + 1 + FBASE(d - SFD_TURN - 2) + SFD_TURN + 1) - 56;  // m = 4
     int m = SFD_TURN + 1;
     const int mend = d - SFD_TURN - 2;
+    int sa = 2 * (W - m), sb = 2 * (W - d + m + 1);
     int dec2 = SF_FAST_BIG;
     for (; m + 7 <= mend; m += 8) {
       int a[8], b[8];
 #pragma unroll
       for (int k = 0; k < 8; k++) {
-        a[k] = fa[ia];
-        b[k] = fb2[ib];
-        ia += W - (m + k);
-        ib -= W - d + (m + k) + 1;
+        a[k] = *(const int16_t *)(pa + (56 - k * (k - 1)));
+        b[k] = *(const int16_t *)(pb + (56 - k * (k - 1)));
+        pa += k < 7 ? sa : sa - 56;  // the last step also rebases for the next batch
+        pb -= k < 7 ? sb : sb + 56;
       }
+      sa -= 16; sb += 16;
 #pragma unroll
       for (int k = 0; k < 8; k += 2) {
         dec = sfd_min(dec, a[k] + b[k]);
@@ -378,9 +380,8 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
       }
     }
     for (; m <= mend; m++) {
-      dec = sfd_min(dec, fa[ia] + fb2[ib]);
-      ia += W - m;
-      ib -= W - d + m + 1;
+      dec = sfd_min(dec, *(const int16_t *)(pa + 56) + *(const int16_t *)(pb + 56));
+      pa += sa; pb -= sb; sa -= 2; sb += 2;
     }
     dec = sfd_min(dec, dec2);
   }

@@ -350,7 +350,7 @@ __global__ __launch_bounds__(SF_DUAL_NT, 2) void sf_mfe_dual_kernel(const uint8_
   XA.tPair = tPair;
   XA.tD5 = tab + 1096; XA.tD3 = tab + 1136;
   XA.S = S0;
-  XA.D = D; XA.F = F; XA.W = W; XA.fml_pad = 0; XA.fst = 2; XA.maxd = D->max_pair_dist;
+  XA.D = D; XA.F = F; XA.W = W; XA.fml_pad = 0; XA.fst = 2; XA.maxd = D->max_pair_dist; XA.cg_ext = 0; XA.tE = nullptr;
   XA.TAU = D->P.TerminalAU; XA.MLbase = D->P.MLbase; XA.MLclosing = D->P.MLclosing; XA.MLintern = D->P.MLintern[1];
   XA.uNIN = nullptr; XA.uIL = nullptr; XA.uL1N = nullptr; XA.uBUL = nullptr;
   XA.cg = cg_all + (size_t)blockIdx.x * 2 * SF_CG_ENTRIES(W);

@@ -39,9 +39,9 @@
 #include "sf_pk16.h"
 
 #define SF_FAST_NR 34
-// 1: the workgroup first builds c + ExtLoop for all cells in LDS (sf_fast_ext_table) and the exterior sweep reads
-// that; 0: the sweep reads the c scratch from device memory (L2) and looks the terms up itself.  Measured on
-// MI355X at W=120: 110.1 ms vs 109.1 ms per 262 144 folds — the table is not worth its two extra barriers.
+// sf_mfe_pk.hip.h only — 1: the workgroup first builds c + ExtLoop for all cells in LDS (sf_fast_ext_table) and the
+// exterior sweep reads that; 0: the sweep reads the c scratch from device memory (L2) and looks the terms up
+// itself.  (This file's kernel publishes c + ExtLoop into the scratch in the first place.)
 #ifndef SF_EXT_TABLE
 #define SF_EXT_TABLE 0
 #endif
@@ -124,7 +124,9 @@ struct SfFastLayout {
   int off_ci, off_c1n, off_cb, off_dml, off_tab, off_red, off_flag, off_S;
   int total;
 };
-#define SF_FAST_TAB_BYTES (5 * 400 + 128 + 80 + 80 + 64 + 4 * 64)
+// int16 entries: mismatch23 rows 0..6 (175), five more mismatch tables rows 1..6 (150 each), stack (64), d5, d3 (40
+// each), pair (64 bytes), one pad, four size tables (32 each)
+#define SF_FAST_TAB_BYTES ((175 + 5 * 150 + 64 + 40 + 40 + 32 + 1 + 4 * 32) * 2)
 static inline __host__ __device__ SfFastLayout sf_fast_layout(int W) {
   SfFastLayout L;
   int tri = (W - 4) * W - (W * (W - 1) / 2 - 6);  // sum_{d=4}^{W-1} (W-d)
@@ -152,6 +154,8 @@ static inline int sf_fast_threads(int W) { return W <= 128 ? 256 : 512; }  // tw
 struct SfFastCtx {
   int16_t *fML, *CI, *C1N, *CB, *DMLr;
   const int16_t *tI, *t1n, *t23, *tM, *tH, *tStack, *tD5, *tD3;
+  const int16_t *tE;  // mismatchExt image (only where cg_ext is set)
+  int cg_ext;         // 1: the c scratch holds c[i,j] + ExtLoop(i,j) (what the exterior sweep adds up); 0: c[i,j]
   const uint8_t *tPair, *S;
   const SfDevParams *D;
   const SfFastParams *F;
@@ -209,6 +213,8 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
 // fML triangle without diagonals 0..3: base(d) = sum_{k=4}^{d-1} (W-k)
 #define FBASE(dd) (((dd)-4) * W - ((dd) * ((dd)-1) / 2 - 6))
 // row of diagonal d-2-u in the rolling tables
+// (a v_readlane lane table for these offsets measured +1 % at W=120, -2 % at W=200, and is unsafe wherever the
+// build spills registers — see SF_UNI — so the scalar unit keeps computing them)
 #define ROW(u) ((slot2 - (u) < 0 ? slot2 - (u) + SF_FAST_NR : slot2 - (u)) * RW)
 
   if (SEC & SF_SEC_P1) {
@@ -436,7 +442,7 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
   // ---- publish the cell ----
   // ---- publish the cell ----
   const int rbd = slotd * RW + i0;
-  int f = SF_FAST_BIG;
+  int f = SF_FAST_BIG, cx = SF_INF16;
   if (type) {
     const int tr = sfd_rtype(type);
     const int sp1 = S[i - 1], sq1 = S[j + 1];
@@ -444,16 +450,21 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
     X.CI[rbd] = (int16_t)(c + X.tI[SF_TIDX(tr, sq1, sp1)]);
     X.C1N[rbd] = (int16_t)(c + X.t1n[SF_TIDX(tr, sq1, sp1)]);
     X.CB[rbd] = (int16_t)(c + tau_in);
-    int stem;  // E_MLstem(type, S[i-1], S[j+1]); sequence ends have dangles only
-    if (i > 1 && j < W) stem = X.tM[SF_TIDX(type, sp1, sq1)];
-    else if (i > 1) stem = X.tD5[type * 5 + sp1];
-    else if (j < W) stem = X.tD3[type * 5 + sq1];
-    else stem = 0;
+    // E_MLstem and ExtLoop of (type, S[i-1], S[j+1]) differ in the mismatch table only; at the sequence ends both
+    // are a dangle
+    int stem, ext;
+    if (i > 1 && j < W) { stem = X.tM[SF_TIDX(type, sp1, sq1)]; ext = X.tE[SF_TIDX(type, sp1, sq1)]; }
+    else if (i > 1) stem = ext = X.tD5[type * 5 + sp1];
+    else if (j < W) stem = ext = X.tD3[type * 5 + sq1];
+    else stem = ext = 0;
     f = c + stem + tau_in + X.MLintern;
+    cx = sfd_min(c + ext + tau_in, SF_INF16);
   } else {
     X.CI[rbd] = SF_INF16; X.C1N[rbd] = SF_INF16; X.CB[rbd] = SF_INF16;
   }
-  X.cg[SF_CGIDX(i, j)] = (int16_t)c;  // row i, column j: the exterior pass reads rows coalesced
+  // the scratch (row i, column j: the exterior sweep reads rows coalesced) takes c + ExtLoop, the only form the
+  // sweep needs; the traceback (native windows only) subtracts the term again (sf_fast_c)
+  X.cg[SF_CGIDX(i, j)] = (int16_t)cx;
   // fML[i,j]: the two neighbours on diagonal d-1 are final only for the even-diagonal group, which gets their
   // minimum (+MLbase) in fnb from its own fix-up of the previous step (see the kernel)
   if (final_fml && d > SFD_TURN + 1) f = sfd_min(f, fnb);
@@ -484,6 +495,21 @@ __device__ __forceinline__ int sf_wave_min(int v) {
 #endif
 }
 
+// c[i,j] from the scratch (which may hold c + ExtLoop, see SfFastCtx::cg_ext)
+__device__ __forceinline__ int sf_fast_c(const SfFastCtx &X, const int16_t *tExt, const int i, const int j) {
+  const int W = X.W;
+  const int v = X.cg[SF_CGIDX(i, j)];
+  if (!X.cg_ext || v >= SF_INF16) return v;
+  const uint8_t *S = X.S;
+  const int type = X.tPair[S[i] * 8 + S[j]];
+  int ext;
+  if (i > 1 && j < W) ext = tExt[SF_TIDX(type, S[i - 1], S[j + 1])];
+  else if (i > 1) ext = X.tD5[type * 5 + S[i - 1]];
+  else if (j < W) ext = X.tD3[type * 5 + S[j + 1]];
+  else ext = 0;
+  return v - ext - (type > 2 ? X.TAU : 0);
+}
+
 // Wave-cooperative traceback over the tables the fill left behind (fML triangle in LDS, c in device memory,
 // f5 in LDS).  Same order of alternatives as sf_mfe_full_kernel / the oracle; candidate
 // tests are spread over the 64 lanes and the first hit in that order is taken with ballot + ffs.
@@ -494,7 +520,7 @@ __device__ inline int sf_fast_traceback(const SfFastCtx &X, const int32_t *f5s, 
   const int W = X.W;
   const uint8_t *S = X.S;
   const SfDevParams *D = X.D;
-#define TC(i, j) ((int)X.cg[SF_CGIDX(i, j)])
+#define TC(i, j) sf_fast_c(X, tExt, (i), (j))
 // diagonals of odd length are followed by one pad entry when X.fml_pad is set
 #define SF_FPADCNT(dd) ((((dd) + (W & 1)) >> 1) - 2)
 #define TF(i, j) (((j) - (i) < SFD_TURN + 1) ? SF_INF16 : (int)X.fML[(FBASE((j) - (i)) + (X.fml_pad ? SF_FPADCNT((j) - (i)) : 0) + (i)-1) * X.fst])
@@ -622,6 +648,12 @@ __device__ inline int sf_fast_traceback(const SfFastCtx &X, const int32_t *f5s, 
   return bad;
 }
 
+#ifdef SF_STAMP
+// diagnostic build only: per-wave cycle totals of block 0 (cell work / barrier 1 / odd finalize / barrier 2 / exterior)
+__device__ unsigned long long sf_stamp_acc[8][8];
+#define SF_T() __builtin_amdgcn_s_memtime()
+#endif
+
 // NG = threads per diagonal group.  The workgroup has two groups: group 0 handles the even diagonals, group 1
 // the odd ones.  c[.,.] of diagonal d+1 does not depend on diagonal d (an enclosed pair spans at most d-1, the
 // multiloop split of d+1 reads fML spans <= d-3), only fML[d+1] needs its two neighbours on d — so the pair
@@ -713,6 +745,9 @@ __device__ __forceinline__ void sf_fast_exterior(const SfFastCtx &X, const int W
     }
     return v;
   };
+#ifdef SF_STAMP
+  const unsigned long long te0 = SF_T();
+#endif
   constexpr int PF = 8;  // rows of c in flight
   int cb[PF][NQ];
   auto load_row = [&](const int i, int(&dst)[NQ]) {
@@ -727,6 +762,7 @@ __device__ __forceinline__ void sf_fast_exterior(const SfFastCtx &X, const int W
 #ifdef SF_ABL_F5
   for (int i0 = W; i0 <= W - SFD_TURN - 1; i0 += PF) {
 #else
+#pragma unroll 1
   for (int i0 = 1; i0 <= W - SFD_TURN - 1; i0 += PF) {
 #endif
 #pragma unroll
@@ -737,7 +773,7 @@ __device__ __forceinline__ void sf_fast_exterior(const SfFastCtx &X, const int W
           f5prev = sfd_min(f5prev, column_min(i - 1));
           if (want_trace && lane == 0) f5s[i - 1] = f5prev;
         }
-        if (etab) {
+        if (etab || X.cg_ext) {
 #pragma unroll
           for (int q = 0; q < NQ; q++) P[q] = sfd_min(P[q], f5prev + cb[k][q]);
         } else {
@@ -762,6 +798,9 @@ __device__ __forceinline__ void sf_fast_exterior(const SfFastCtx &X, const int W
       }
     }
   }
+#ifdef SF_STAMP
+  const unsigned long long te1 = SF_T();
+#endif
   // the last columns: every row has been seen
   for (int jf = sfd_max(W - SFD_TURN - 1, 1); jf <= W; jf++) {
     f5prev = sfd_min(f5prev, column_min(jf));
@@ -776,6 +815,12 @@ __device__ __forceinline__ void sf_fast_exterior(const SfFastCtx &X, const int W
       ovf_list[k] = seq;
     }
   }
+#ifdef SF_STAMP
+  if (blockIdx.x == 0 && lane == 0) {
+    const unsigned long long te2 = SF_T();
+    sf_stamp_acc[4][0] += te1 - te0; sf_stamp_acc[4][1] += te2 - te1;
+  }
+#endif
   // ---- traceback for the sequences whose structure is wanted (native windows) ----
   if (db_out && !over && (seq % trace_stride) == 0) {
     int16_t *stI = stack_area;
@@ -787,12 +832,6 @@ __device__ __forceinline__ void sf_fast_exterior(const SfFastCtx &X, const int W
     if (bad && lane == 0) atomicOr(status, 1);
   }
 }
-
-#ifdef SF_STAMP
-// diagnostic build only: per-wave cycle totals of block 0 (cell work / barrier 1 / odd finalize / barrier 2 / exterior)
-__device__ unsigned long long sf_stamp_acc[8][8];
-#define SF_T() __builtin_amdgcn_s_memtime()
-#endif
 
 template <int NG, int WT>
 __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_kernel(const uint8_t *__restrict__ seqs, int n, int Wrt,
@@ -814,9 +853,13 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
   X.CB = (int16_t *)(smem + Lo.off_cb);
   X.DMLr = (int16_t *)(smem + Lo.off_dml);
   int16_t *tab = (int16_t *)(smem + Lo.off_tab);
-  X.tI = tab; X.t1n = tab + 200; X.t23 = tab + 400; X.tM = tab + 600; X.tH = tab + 800;
-  X.tStack = tab + 1000; X.tD5 = tab + 1064; X.tD3 = tab + 1104;
-  uint8_t *tPair = (uint8_t *)(tab + 1144);
+  // Pair types are 1..6, so only those rows of a [type][5][5] table exist here and the pointers are biased by
+  // one row.  mismatch23 keeps its (zero) row 0: it is also indexed with the type of an enclosed cell that may
+  // not pair (the sum stays >= INF through the cell's table entry).
+  X.t23 = tab; X.tI = tab + 175 - 25; X.t1n = tab + 325 - 25; X.tM = tab + 475 - 25; X.tH = tab + 625 - 25;
+  X.tE = tab + 775 - 25; X.cg_ext = 1;
+  X.tStack = tab + 925; X.tD5 = tab + 989; X.tD3 = tab + 1029;
+  uint8_t *tPair = (uint8_t *)(tab + 1069);
   X.tPair = tPair;
   (void)Lo.off_red;
   int32_t *flag = (int32_t *)(smem + Lo.off_flag);
@@ -831,15 +874,18 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
   const int tid = threadIdx.x;
   X.cg = cg_all + (size_t)blockIdx.x * SF_CG_ENTRIES(W);  // c by (row i, column j), triangular
   // parameter tables -> LDS, once per workgroup
-  for (int x = tid; x < 200; x += NT) {
-    tab[x] = F->mmI[x]; tab[200 + x] = F->mm1n[x]; tab[400 + x] = F->mm23[x]; tab[600 + x] = F->mmM[x];
-    tab[800 + x] = F->mmH[x];
+  for (int x = tid; x < 175; x += NT) {
+    tab[x] = F->mm23[x];
+    if (x < 150) {
+      tab[175 + x] = F->mmI[25 + x]; tab[325 + x] = F->mm1n[25 + x]; tab[475 + x] = F->mmM[25 + x];
+      tab[625 + x] = F->mmH[25 + x]; tab[775 + x] = F->mmExt[25 + x];
+    }
   }
-  for (int x = tid; x < 64; x += NT) { tab[1000 + x] = F->stack[x]; tPair[x] = F->pair[x]; }
-  for (int x = tid; x < 40; x += NT) { tab[1064 + x] = F->d5[x]; tab[1104 + x] = F->d3[x]; }
+  for (int x = tid; x < 64; x += NT) { tab[925 + x] = F->stack[x]; tPair[x] = F->pair[x]; }
+  for (int x = tid; x < 40; x += NT) { tab[989 + x] = F->d5[x]; tab[1029 + x] = F->d3[x]; }
 
   {
-    int16_t *uni = tab + 1144 + 32;  // after the 64-byte pair table
+    int16_t *uni = tab + 1069 + 32 + 1;  // after the 64-byte pair table, at an even index (read as 32-bit pairs)
     X.uNIN = uni; X.uIL = uni + 32; X.uL1N = uni + 64; X.uBUL = uni + 96;
     for (int x = tid; x < 32; x += NT) {
       uni[x] = (int16_t)sfd_min(F->NIN[x], 32000); uni[32 + x] = (int16_t)sfd_min(F->IL[x], 32000);
@@ -898,6 +944,9 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
           if (valid) X.C1N[slotd * (W - 4) + i - 1] = (int16_t)sfd_min(eh, 32000);
         }
       }
+#ifdef SF_STAMP
+      const unsigned long long tA = SF_T();
+#endif
       if (split) {
         __syncthreads();
         if (!helper && __ballot(valid)) {
@@ -940,7 +989,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
         const int w = tid >> 6;
         sf_stamp_acc[w][0] += t1 - t0; sf_stamp_acc[w][1] += t2 - t1; sf_stamp_acc[w][2] += t3 - t2;
         sf_stamp_acc[w][5] += 1;
-        if (d0 >= 56) { sf_stamp_acc[w][6] += t1 - t0; sf_stamp_acc[w][7] += 1; }
+        if (d0 >= 58) { sf_stamp_acc[w][6] += t1 - t0; sf_stamp_acc[w][7] += 1; sf_stamp_acc[w][3] += tA - t0; }
       }
 #endif
       slot2 += 2; if (slot2 >= SF_FAST_NR) slot2 -= SF_FAST_NR;
@@ -948,26 +997,19 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
     }
 
     // ---- exterior loop f5[j] = min(f5[j-1], min_i f5[i-1] + c[i,j] + ExtLoop(i,j)) : wave 0 only ----
-    // lane l owns i = l+1, l+65, ...; f5[i-1] sits in its registers, c rows stream from device memory
-    // (one row ahead), the minimum over i is a wave butterfly.  No workgroup barrier inside the loop.
+    // (sf_fast_exterior: lane = column, rows of c + ExtLoop stream from the scratch a few rows ahead)
 #ifdef SF_STAMP
     const unsigned long long tf0 = SF_T();
 #endif
     if (ovf) flag[0] = 1;
     for (int x = tid; x < 200; x += NT) tExt[x] = F->mmExt[x];
     __syncthreads();
-    // The rolling tables are dead now.  When a table of c + ExtLoop fits into the CI + C1N areas behind f5[] and the
-    // mismatchExt table, the whole workgroup builds it in LDS (sf_fast_ext_table), so the single-wave exterior
-    // sweep neither waits for device memory nor looks anything up.
+    // (the scratch already holds c + ExtLoop: the sweep is one add and one min per cell; the mismatchExt table
+    // above is for the traceback)
     int16_t *etab = nullptr;
-    {
-      const int e_off = (int)(((char *)tExt - smem) + 400 + 3) & ~3;
-      if (SF_EXT_TABLE && e_off + SF_CG_ENTRIES(W) * 2 <= Lo.off_cb) {
-        etab = (int16_t *)(smem + e_off);
-        sf_fast_ext_table(X, W, tid, NT, tExt, etab);
-      }
-    }
-    __syncthreads();
+#ifdef SF_STAMP
+    if (blockIdx.x == 0 && tid == 0) sf_stamp_acc[4][2] += SF_T() - tf0;
+#endif
     if (tid < 64)
       sf_fast_exterior<NG / 64>(X, W, tid, seq, f5s, tExt, etab, flag, (int16_t *)(smem + Lo.off_cb),
                       (char *)(smem + Lo.off_cb + ((3 * (W + 8) * 2 + 3) & ~3)), out, ovf_cnt, ovf_list, trace_stride,

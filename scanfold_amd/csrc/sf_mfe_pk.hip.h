@@ -380,7 +380,7 @@ __global__ __launch_bounds__(128, 2) void sf_mfe_pk_kernel(const uint8_t *__rest
   int32_t *flag = (int32_t *)(smem + Lo.off_flag);
   uint8_t *S = (uint8_t *)(smem + Lo.off_S);
   X.S = S;
-  X.D = D; X.F = F; X.W = W; X.fml_pad = 1; X.fst = 1; X.maxd = D->max_pair_dist;
+  X.D = D; X.F = F; X.W = W; X.fml_pad = 1; X.fst = 1; X.maxd = D->max_pair_dist; X.cg_ext = 0; X.tE = nullptr;
   X.TAU = D->P.TerminalAU; X.MLbase = D->P.MLbase; X.MLclosing = D->P.MLclosing; X.MLintern = D->P.MLintern[1];
   // exterior pass aliases (the rolling CI area is dead by then)
   int32_t *f5s = (int32_t *)(smem + Lo.off_ci);

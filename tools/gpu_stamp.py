@@ -12,7 +12,9 @@ eng.lib.sf_debug_stamps.argtypes = [ctypes.c_void_p]
 eng.lib.sf_debug_stamps(out)
 a = np.array(list(out), dtype=np.float64).reshape(8, 8)
 nfold = 65536 / 1024
-print("per fold (block 0), s_memtime ticks: cell | barrier1 | oddfinal | barrier2 | exterior+trace | steps | cell(d0>=56) | steps(d0>=56)")
+print("per fold (block 0), s_memtime ticks: cell | barrier1 | oddfinal | pre-exchange(d0>=58) | exterior+trace | steps | cell(d0>=58) | steps(d0>=58)")
+print('exterior (wave 0): sweep | last columns + result | table fill + barriers before the sweep')
+print(' '.join('%9.0f' % x for x in a[4][:3] / nfold))
 for w in range(4):
     r = a[w] / nfold
     print("wave", w, " ".join("%9.0f" % x for x in r))

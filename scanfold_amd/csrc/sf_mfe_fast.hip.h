@@ -45,6 +45,8 @@
 #ifndef SF_EXT_TABLE
 #define SF_EXT_TABLE 0
 #endif
+// even diagonals below this one run the size-tested cell code (some special loops do not exist yet: d <= 11)
+#define SF_FAST_TINY_D0 12
 #ifndef SF_FAST_SPLIT
 #define SF_FAST_SPLIT 1  // long diagonals: the idle second wave of a group takes part of the cell's work
 #endif
@@ -122,6 +124,7 @@ static inline void sf_fast_build_params(const SfDevParams &D, SfFastParams &F) {
 struct SfFastLayout {
   int tri;  // int16 entries of the fML triangle (diagonals >= 4)
   int off_ci, off_c1n, off_cb, off_dml, off_tab, off_red, off_flag, off_S;
+  int off_guard;  // per-wave copies of the size tables for the short diagonals (sf_fast_guard_tables)
   int total;
 };
 // int16 entries: mismatch23 rows 0..6 (175), five more mismatch tables rows 1..6 (150 each), stack (64), d5, d3 (40
@@ -144,6 +147,11 @@ static inline __host__ __device__ SfFastLayout sf_fast_layout(int W) {
   L.off_red = o;  // (unused)
   L.off_flag = o; o += 4;
   L.off_S = o; o += (W + 2 + 3) & ~3;
+  // 256 bytes per wave, needed while d < 36 only: from W = 96 on they lie in the end of the fML triangle, whose
+  // last 45 diagonals (>= 2 kB from W = 96 on, first written at d = W-45 >= 51) are still unused by then
+  const int guard_bytes = (W <= 128 ? 4 : 8) * 256;
+  if (W >= 96) L.off_guard = tri * 2 - guard_bytes;
+  else { L.off_guard = o; o += guard_bytes; }
   L.total = o;
   return L;
 }
@@ -197,7 +205,10 @@ enum { SF_SEC_P1 = 1, SF_SEC_HELP = 2, SF_SEC_DML = 4, SF_SEC_FIN = 8, SF_SEC_C0
 template <bool G, int WT, int SEC>
 __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, const int i, const bool valid,
                                              const int slot2, const int slotd, uint32_t (&HP)[14], int &ovf,
-                                             const bool final_fml, const int fnb, int &fpart, int &dec, int &eh, int &e0) {
+                                             const bool final_fml, const int fnb, int &fpart, int &dec, int &eh, int &e0,
+                                             const int16_t *uni) {
+  // size tables [4][32]: asymmetry, loop initiation, 1xn, bulge (the kernel passes guarded copies on short diagonals)
+  const int16_t *const uNIN = uni, *const uIL = uni + 32, *const uL1N = uni + 64, *const uBUL = uni + 96;
 // H[x] (x = size - 4) lives in the int16 halves of HP[x/2]: 14 registers instead of 27 under the 128-VGPR cap
 #define HGET(x) (((x)&1) ? ((int)HP[(x) >> 1] >> 16) : (int)(int16_t)(HP[(x) >> 1] & 0xffffu))
 #define HSET(x, v)                                                                                       \
@@ -225,7 +236,7 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
     for (int u = 30; u >= 6; --u) {
       if (u <= umax) {
         const int16_t *row = X.CI + ROW(u) + i0;
-        const int e = sfd_min(row[3], row[u - 1]) + SF_UNI(X.uNIN, u - 4);  // u1 = 2 and u2 = 2
+        const int e = sfd_min(row[3], row[u - 1]) + SF_UNI(uNIN, u - 4);  // u1 = 2 and u2 = 2
         HSET(u - 4, sfd_min(e, HGET(u - 6)));
       }
     }
@@ -236,7 +247,7 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
     // HP[p-1] still holds the enclosed cell's minima.  Size 30 (x = 26) has no partner.
     {
       const int16_t *row = X.CI + ROW(30) + i0;
-      const int e = sfd_min(row[3], row[29]) + SF_UNI(X.uNIN, 26);
+      const int e = sfd_min(row[3], row[29]) + SF_UNI(uNIN, 26);
       HSET(26, sfd_min(e, HGET(24)));
     }
 #pragma unroll
@@ -248,7 +259,7 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
         const int16_t *ra = X.CI + ROW(u) + i0, *rb = X.CI + ROW(u + 1) + i0;
         e1[k] = sf_pk(ra[3], rb[3]);          // u1 = 2
         e2[k] = sf_pk(ra[u - 1], rb[u]);      // u2 = 2
-        nn[k] = sf_ldw(X.uNIN + (u - 4));
+        nn[k] = sf_ldw(uNIN + (u - 4));
       }
 #pragma unroll
       for (int k = 0; k < 3; k++) {
@@ -259,9 +270,9 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
   }
   if (!G || umax >= 5) {
     const int16_t *row = X.CI + ROW(5) + i0;
-    HSET(1, sfd_min(row[3], row[4]) + SF_UNI(X.uNIN, 1));
+    HSET(1, sfd_min(row[3], row[4]) + SF_UNI(uNIN, 1));
   }
-  if (!G || umax >= 4) HSET(0, X.CI[ROW(4) + i0 + 3] + SF_UNI(X.uNIN, 0));
+  if (!G || umax >= 4) HSET(0, X.CI[ROW(4) + i0 + 3] + SF_UNI(uNIN, 0));
 #endif
 
   }
@@ -280,7 +291,7 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
         eh = sfd_min(eh, X.CB[ROW(0) + i0 + 1] - (t2r > 2 ? TAU : 0) + st[t2r]);
       }
       if (!G || umax >= 1) {  // one-nucleotide bulges keep the stack
-        const int b1 = SF_UNI(X.uBUL, 1);
+        const int b1 = SF_UNI(uBUL, 1);
         const int16_t *row = X.CB + ROW(1) + i0;
         const int ta = sfd_rtype(X.tPair[si1 * 8 + S[j - 2]]);  // (i+1, j-2)
         eh = sfd_min(eh, row[1] - (ta > 2 ? TAU : 0) + b1 + st[ta]);
@@ -319,8 +330,8 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
         for (int u = 2; u <= 30; ++u) {
           if (u <= umax) {
             const int rw = ROW(u) + i0;
-            gb = sfd_min(gb, sfd_min(X.CB[rw + 1], X.CB[rw + 1 + u]) + SF_UNI(X.uBUL, u));
-            if (u >= 4) g1 = sfd_min(g1, sfd_min(X.C1N[rw + 2], X.C1N[rw + u]) + SF_UNI(X.uL1N, u - 1));
+            gb = sfd_min(gb, sfd_min(X.CB[rw + 1], X.CB[rw + 1 + u]) + SF_UNI(uBUL, u));
+            if (u >= 4) g1 = sfd_min(g1, sfd_min(X.C1N[rw + 2], X.C1N[rw + u]) + SF_UNI(uL1N, u - 1));
           }
         }
       } else {
@@ -333,8 +344,8 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
             const int u = ub + k;
             if (u <= 30) {
               const int rw = ROW(u) + i0;
-              b1[k] = X.CB[rw + 1]; b2[k] = X.CB[rw + 1 + u]; tb[k] = SF_UNI(X.uBUL, u);
-              if (u >= 4) { n1[k] = X.C1N[rw + 2]; n2[k] = X.C1N[rw + u]; tn[k] = SF_UNI(X.uL1N, u - 1); }
+              b1[k] = X.CB[rw + 1]; b2[k] = X.CB[rw + 1 + u]; tb[k] = SF_UNI(uBUL, u);
+              if (u >= 4) { n1[k] = X.C1N[rw + 2]; n2[k] = X.C1N[rw + u]; tn[k] = SF_UNI(uL1N, u - 1); }
             }
           }
 #pragma unroll
@@ -408,13 +419,13 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
         if (G) {
 #pragma unroll
           for (int u = 6; u <= 30; ++u)
-            if (u <= umax) gg = sfd_min(gg, HGET(u - 4) + SF_UNI(X.uIL, u));
+            if (u <= umax) gg = sfd_min(gg, HGET(u - 4) + SF_UNI(uIL, u));
         } else {
           // generic minima plus loop initiation, two sizes per packed add / min (size 31 does not exist: its
           // half of HP[13] stays INF)
           uint32_t ggp = sf_pk(32767, 32767);
 #pragma unroll
-          for (int pp = 1; pp <= 13; pp++) ggp = sf_pkmin(ggp, sf_pkadd(HP[pp], sf_ldw(X.uIL + 2 * pp + 4)));
+          for (int pp = 1; pp <= 13; pp++) ggp = sf_pkmin(ggp, sf_pkadd(HP[pp], sf_ldw(uIL + 2 * pp + 4)));
           gg = sfd_min(sf_lo(ggp), sf_hi(ggp));
         }
 #endif
@@ -651,6 +662,7 @@ __device__ inline int sf_fast_traceback(const SfFastCtx &X, const int32_t *f5s, 
 #ifdef SF_STAMP
 // diagnostic build only: per-wave cycle totals of block 0 (cell work / barrier 1 / odd finalize / barrier 2 / exterior)
 __device__ unsigned long long sf_stamp_acc[8][8];
+__device__ unsigned long long sf_stamp_step[128];  // wave 0 of block 0: whole step (cell .. odd finalize) by d0/2
 #define SF_T() __builtin_amdgcn_s_memtime()
 #endif
 
@@ -860,6 +872,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
   X.tE = tab + 775 - 25; X.cg_ext = 1;
   X.tStack = tab + 925; X.tD5 = tab + 989; X.tD3 = tab + 1029;
   uint8_t *tPair = (uint8_t *)(tab + 1069);
+  int16_t *guard = (int16_t *)(smem + Lo.off_guard);
   X.tPair = tPair;
   (void)Lo.off_red;
   int32_t *flag = (int32_t *)(smem + Lo.off_flag);
@@ -892,6 +905,9 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
       uni[64 + x] = (int16_t)sfd_min(F->L1N[x], 32000); uni[96 + x] = (int16_t)sfd_min(F->BUL[x], 32000);
     }
   }
+  // the rolling tables start out as "no structure": the guarded short-diagonal code reads rows no diagonal of the
+  // first fold has written yet (later folds find the previous fold's energies there, which is as good)
+  for (int x = tid; x < (Lo.off_dml - Lo.off_ci) / 2; x += NT) X.CI[x] = SF_INF16;
   // group and centre-based mapping inside the group: v = (tg + OFF) mod NG, cell i = v - d/2
   const int grp = SF_WAVE_UNIFORM(tid / NG);  // a wave lies in one group: keep d, row slots, loop limits scalar
   const int tg = tid - grp * NG;
@@ -928,6 +944,23 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
       const bool valid = (d < W) && (i >= 1) && (i + d <= W);
       int fpart = SF_FAST_BIG;
       int dec = SF_FAST_BIG, eh = SF_FAST_BIG, e0 = SF_FAST_BIG;
+      // Short diagonals (d < 36): loop sizes above d-6 do not exist.  Instead of testing every size (a branch per
+      // size, nothing in flight across it), the cell runs the same straight-line code as on long diagonals with
+      // this wave's copy of the size tables in which those sizes cost 32767: their candidates (stale but
+      // energy-sized table entries) saturate / stay far above every real one.
+      const int16_t *uni = X.uNIN;
+      if (d0 >= SF_FAST_TINY_D0 && d0 < SFD_MAXLOOP + 6) {
+        int16_t *gt = guard + (tid >> 6) * 128;
+        const int um = d - 2 - (SFD_TURN + 1);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const int e = (tid & 63) + 64 * h, t = e >> 5, idx = e & 31;
+          const int lim = um - (t == 0 ? 4 : (t == 2 ? 1 : 0));  // NIN[u-4], IL[u], L1N[u-1], BUL[u]
+          gt[e] = idx <= lim ? X.uNIN[e] : (int16_t)32767;
+        }
+        SF_WAVE_SYNC();
+        uni = gt;
+      }
 #ifdef SF_STAMP
       const unsigned long long t0 = SF_T();
 #endif
@@ -936,11 +969,11 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
 #else
       if (__ballot(valid)) {
 #endif
-        if (d0 < SFD_MAXLOOP + 6) sf_fast_cell<true, WT, SF_SEC_ALL>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0);
-        else if (!split) sf_fast_cell<false, WT, SF_SEC_ALL>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0);
-        else if (!helper) sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_DML>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0);
+        if (d0 < SF_FAST_TINY_D0) sf_fast_cell<true, WT, SF_SEC_ALL>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni);
+        else if (!split) sf_fast_cell<false, WT, SF_SEC_ALL>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni);
+        else if (!helper) sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_DML>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni);
         else {
-          sf_fast_cell<false, WT, SF_SEC_HELP>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0);
+          sf_fast_cell<false, WT, SF_SEC_HELP>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni);
           if (valid) X.C1N[slotd * (W - 4) + i - 1] = (int16_t)sfd_min(eh, 32000);
         }
       }
@@ -951,7 +984,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
         __syncthreads();
         if (!helper && __ballot(valid)) {
           if (valid) eh = X.C1N[slotd * (W - 4) + i - 1];
-          sf_fast_cell<false, WT, SF_SEC_FIN>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0);
+          sf_fast_cell<false, WT, SF_SEC_FIN>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni);
         }
       }
 #ifdef SF_STAMP
@@ -989,6 +1022,8 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
         const int w = tid >> 6;
         sf_stamp_acc[w][0] += t1 - t0; sf_stamp_acc[w][1] += t2 - t1; sf_stamp_acc[w][2] += t3 - t2;
         sf_stamp_acc[w][5] += 1;
+        if (w == 0) sf_stamp_step[d0 >> 1] += t3 - t0;
+        if (w == 1) sf_stamp_step[64 + (d0 >> 1)] += tA - t0;
         if (d0 >= 58) { sf_stamp_acc[w][6] += t1 - t0; sf_stamp_acc[w][7] += 1; sf_stamp_acc[w][3] += tA - t0; }
       }
 #endif

@@ -173,6 +173,8 @@ struct SfFastCtx {
   int maxd;     // largest allowed j - i of a base pair (max_bp_span - 1)
   int fst;      // element stride of fML (2 when two folds are interleaved, sf_mfe_dual.hip.h)
   const int16_t *uNIN, *uIL, *uL1N, *uBUL;  // size-dependent terms, LDS copies (uniform reads)
+  int16_t *BN;  // sf_mfe_fast_kernel: the bulge and 1xn rolling tables interleaved, entry x = (CB[x], C1N[x]) in one
+                // 32-bit word (CB / C1N above stay null there); uNIN = [NIN 32][IL 32][(BUL[u], L1N[u-1]) 32 pairs]
 };
 
 #define SF_TIDX(t, a, b) ((t)*25 + (a)*5 + (b))
@@ -208,7 +210,10 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
                                              const bool final_fml, const int fnb, int &fpart, int &dec, int &eh, int &e0,
                                              const int16_t *uni) {
   // size tables [4][32]: asymmetry, loop initiation, 1xn, bulge (the kernel passes guarded copies on short diagonals)
-  const int16_t *const uNIN = uni, *const uIL = uni + 32, *const uL1N = uni + 64, *const uBUL = uni + 96;
+  // third table: 32-bit pairs (bulge[u], 1xn term of total size u — 32767 for u < 4, where no 1xn loop exists)
+  const int16_t *const uNIN = uni, *const uIL = uni + 32, *const uBN = uni + 64;
+#define CBAT(x) X.BN[2 * (x)]
+#define C1NAT(x) X.BN[2 * (x) + 1]
 // H[x] (x = size - 4) lives in the int16 halves of HP[x/2]: 14 registers instead of 27 under the 128-VGPR cap
 #define HGET(x) (((x)&1) ? ((int)HP[(x) >> 1] >> 16) : (int)(int16_t)(HP[(x) >> 1] & 0xffffu))
 #define HSET(x, v)                                                                                       \
@@ -288,38 +293,38 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
 #ifndef SF_ABL_RARE
       {  // stack
         const int t2r = sfd_rtype(X.tPair[si1 * 8 + sj1]);
-        eh = sfd_min(eh, X.CB[ROW(0) + i0 + 1] - (t2r > 2 ? TAU : 0) + st[t2r]);
+        eh = sfd_min(eh, CBAT(ROW(0) + i0 + 1) - (t2r > 2 ? TAU : 0) + st[t2r]);
       }
       if (!G || umax >= 1) {  // one-nucleotide bulges keep the stack
-        const int b1 = SF_UNI(uBUL, 1);
-        const int16_t *row = X.CB + ROW(1) + i0;
+        const int b1 = SF_UNI(uBN, 2);
+        const int16_t *row = X.BN + 2 * (ROW(1) + i0);
         const int ta = sfd_rtype(X.tPair[si1 * 8 + S[j - 2]]);  // (i+1, j-2)
-        eh = sfd_min(eh, row[1] - (ta > 2 ? TAU : 0) + b1 + st[ta]);
+        eh = sfd_min(eh, row[2 * 1] - (ta > 2 ? TAU : 0) + b1 + st[ta]);
         const int tb = sfd_rtype(X.tPair[S[i + 2] * 8 + sj1]);  // (i+2, j-1)
-        eh = sfd_min(eh, row[2] - (tb > 2 ? TAU : 0) + b1 + st[tb]);
+        eh = sfd_min(eh, row[2 * 2] - (tb > 2 ? TAU : 0) + b1 + st[tb]);
       }
       if (!G || umax >= 2) {  // 1 x 1: (i+2, j-2)
         const int t2r = sfd_rtype(X.tPair[S[i + 2] * 8 + S[j - 2]]);
-        eh = sfd_min(eh, X.CB[ROW(2) + i0 + 2] - (t2r > 2 ? TAU : 0) + P.int11[type][t2r][si1][sj1]);
+        eh = sfd_min(eh, CBAT(ROW(2) + i0 + 2) - (t2r > 2 ? TAU : 0) + P.int11[type][t2r][si1][sj1]);
       }
       if (!G || umax >= 3) {  // 1 x 2 and 2 x 1
-        const int16_t *row = X.CB + ROW(3) + i0;
+        const int16_t *row = X.BN + 2 * (ROW(3) + i0);
         const int ta = sfd_rtype(X.tPair[S[i + 2] * 8 + S[j - 3]]);  // (i+2, j-3), sq1 = S[j-2]
-        eh = sfd_min(eh, row[2] - (ta > 2 ? TAU : 0) + P.int21[type][ta][si1][S[j - 2]][sj1]);
+        eh = sfd_min(eh, row[2 * 2] - (ta > 2 ? TAU : 0) + P.int21[type][ta][si1][S[j - 2]][sj1]);
         const int tb = sfd_rtype(X.tPair[S[i + 3] * 8 + S[j - 2]]);  // (i+3, j-2), sp1 = S[i+2]
-        eh = sfd_min(eh, row[3] - (tb > 2 ? TAU : 0) + P.int21[tb][type][sj1][si1][S[i + 2]]);
+        eh = sfd_min(eh, row[2 * 3] - (tb > 2 ? TAU : 0) + P.int21[tb][type][sj1][si1][S[i + 2]]);
       }
       if (!G || umax >= 4) {  // 2 x 2: (i+3, j-3)
         const int t2r = sfd_rtype(X.tPair[S[i + 3] * 8 + S[j - 3]]);
-        eh = sfd_min(eh, X.CB[ROW(4) + i0 + 3] - (t2r > 2 ? TAU : 0) + P.int22[type][t2r][si1][S[i + 2]][S[j - 2]][sj1]);
+        eh = sfd_min(eh, CBAT(ROW(4) + i0 + 3) - (t2r > 2 ? TAU : 0) + P.int22[type][t2r][si1][S[i + 2]][S[j - 2]][sj1]);
       }
       if (!G || umax >= 5) {  // 2 x 3 and 3 x 2
-        const int16_t *row = X.CB + ROW(5) + i0;
+        const int16_t *row = X.BN + 2 * (ROW(5) + i0);
         const int m23 = X.t23[SF_TIDX(type, si1, sj1)] + X.F->L23;
         const int ta = sfd_rtype(X.tPair[S[i + 3] * 8 + S[j - 4]]);  // (i+3, j-4); sp1 = S[i+2], sq1 = S[j-3]
-        eh = sfd_min(eh, row[3] - (ta > 2 ? TAU : 0) + m23 + X.t23[SF_TIDX(ta, S[j - 3], S[i + 2])]);
+        eh = sfd_min(eh, row[2 * 3] - (ta > 2 ? TAU : 0) + m23 + X.t23[SF_TIDX(ta, S[j - 3], S[i + 2])]);
         const int tb = sfd_rtype(X.tPair[S[i + 4] * 8 + S[j - 3]]);  // (i+4, j-3); sp1 = S[i+3], sq1 = S[j-2]
-        eh = sfd_min(eh, row[4] - (tb > 2 ? TAU : 0) + m23 + X.t23[SF_TIDX(tb, S[j - 2], S[i + 3])]);
+        eh = sfd_min(eh, row[2 * 4] - (tb > 2 ? TAU : 0) + m23 + X.t23[SF_TIDX(tb, S[j - 2], S[i + 3])]);
       }
 #endif
       // bulges (size u >= 2) and 1 x n loops (total size u >= 4), one rolling row per u
@@ -330,33 +335,40 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
         for (int u = 2; u <= 30; ++u) {
           if (u <= umax) {
             const int rw = ROW(u) + i0;
-            gb = sfd_min(gb, sfd_min(X.CB[rw + 1], X.CB[rw + 1 + u]) + SF_UNI(uBUL, u));
-            if (u >= 4) g1 = sfd_min(g1, sfd_min(X.C1N[rw + 2], X.C1N[rw + u]) + SF_UNI(uL1N, u - 1));
+            gb = sfd_min(gb, sfd_min(CBAT(rw + 1), CBAT(rw + 1 + u)) + SF_UNI(uBN, 2 * u));
+            if (u >= 4) g1 = sfd_min(g1, sfd_min(C1NAT(rw + 2), C1NAT(rw + u)) + SF_UNI(uBN, 2 * u + 1));
           }
         }
       } else {
-        // batches of two sizes = 12 LDS reads in flight
+        // The candidates of size u are CB[1], CB[1+u] and C1N[2], C1N[u] of row u: with the two tables interleaved
+        // they are the low / high halves of the word pairs (1, 2) and (u, u+1) — two two-word reads; one
+        // bit-select each puts (bulge, 1xn) candidates side by side, and the rest is packed: min, saturating
+        // add of the (bulge[u], 1xn[u]) weights (one uniform read), min.  Batches of two sizes.
+        uint32_t acc = sf_pk(32767, 32767);
 #pragma unroll
         for (int ub = 2; ub <= 30; ub += 2) {
-          int b1[2], b2[2], n1[2], n2[2], tb[2], tn[2];
+          uint32_t w0[2], w1[2], w2[2], w3[2], wt[2];
 #pragma unroll
           for (int k = 0; k < 2; k++) {
             const int u = ub + k;
             if (u <= 30) {
-              const int rw = ROW(u) + i0;
-              b1[k] = X.CB[rw + 1]; b2[k] = X.CB[rw + 1 + u]; tb[k] = SF_UNI(uBUL, u);
-              if (u >= 4) { n1[k] = X.C1N[rw + 2]; n2[k] = X.C1N[rw + u]; tn[k] = SF_UNI(uL1N, u - 1); }
+              const int16_t *t = X.BN + 2 * (ROW(u) + i0);
+              w0[k] = sf_ldw(t + 2 * 1); w1[k] = sf_ldw(t + 2 * 2);
+              w2[k] = sf_ldw(t + 2 * u); w3[k] = sf_ldw(t + 2 * (u + 1));
+              wt[k] = sf_ldw(uBN + 2 * u);
             }
           }
 #pragma unroll
           for (int k = 0; k < 2; k++) {
             const int u = ub + k;
             if (u <= 30) {
-              gb = sfd_min(gb, sfd_min(b1[k], b2[k]) + tb[k]);
-              if (u >= 4) g1 = sfd_min(g1, sfd_min(n1[k], n2[k]) + tn[k]);
+              const uint32_t x = (w0[k] & 0xffffu) | (w1[k] & 0xffff0000u);  // (CB[1], C1N[2])
+              const uint32_t y = (w3[k] & 0xffffu) | (w2[k] & 0xffff0000u);  // (CB[1+u], C1N[u])
+              acc = sf_pkmin(acc, sf_pkadd(sf_pkmin(x, y), wt[k]));
             }
           }
         }
+        gb = sf_lo(acc); g1 = sf_hi(acc);
       }
 #endif
       eh = sfd_min(eh, gb + tau_out);
@@ -459,8 +471,7 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
     const int sp1 = S[i - 1], sq1 = S[j + 1];
     const int tau_in = tr > 2 ? X.TAU : 0;
     X.CI[rbd] = (int16_t)(c + X.tI[SF_TIDX(tr, sq1, sp1)]);
-    X.C1N[rbd] = (int16_t)(c + X.t1n[SF_TIDX(tr, sq1, sp1)]);
-    X.CB[rbd] = (int16_t)(c + tau_in);
+    sf_stw(X.BN + 2 * rbd, sf_pk(c + tau_in, c + X.t1n[SF_TIDX(tr, sq1, sp1)]));  // (CB, C1N)
     // E_MLstem and ExtLoop of (type, S[i-1], S[j+1]) differ in the mismatch table only; at the sequence ends both
     // are a dangle
     int stem, ext;
@@ -471,7 +482,7 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
     f = c + stem + tau_in + X.MLintern;
     cx = sfd_min(c + ext + tau_in, SF_INF16);
   } else {
-    X.CI[rbd] = SF_INF16; X.C1N[rbd] = SF_INF16; X.CB[rbd] = SF_INF16;
+    X.CI[rbd] = SF_INF16; sf_stw(X.BN + 2 * rbd, sf_pk(SF_INF16, SF_INF16));
   }
   // the scratch (row i, column j: the exterior sweep reads rows coalesced) takes c + ExtLoop, the only form the
   // sweep needs; the traceback (native windows only) subtracts the term again (sf_fast_c)
@@ -861,8 +872,8 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
   SfFastCtx X;
   X.fML = (int16_t *)smem;
   X.CI = (int16_t *)(smem + Lo.off_ci);
-  X.C1N = (int16_t *)(smem + Lo.off_c1n);
-  X.CB = (int16_t *)(smem + Lo.off_cb);
+  X.C1N = nullptr; X.CB = nullptr;
+  X.BN = (int16_t *)(smem + Lo.off_c1n);  // spans the two areas
   X.DMLr = (int16_t *)(smem + Lo.off_dml);
   int16_t *tab = (int16_t *)(smem + Lo.off_tab);
   // Pair types are 1..6, so only those rows of a [type][5][5] table exist here and the pointers are biased by
@@ -899,10 +910,11 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
 
   {
     int16_t *uni = tab + 1069 + 32 + 1;  // after the 64-byte pair table, at an even index (read as 32-bit pairs)
-    X.uNIN = uni; X.uIL = uni + 32; X.uL1N = uni + 64; X.uBUL = uni + 96;
+    X.uNIN = uni; X.uIL = uni + 32; X.uL1N = nullptr; X.uBUL = nullptr;  // (uni + 64: the pair table, see SfFastCtx::BN)
     for (int x = tid; x < 32; x += NT) {
       uni[x] = (int16_t)sfd_min(F->NIN[x], 32000); uni[32 + x] = (int16_t)sfd_min(F->IL[x], 32000);
-      uni[64 + x] = (int16_t)sfd_min(F->L1N[x], 32000); uni[96 + x] = (int16_t)sfd_min(F->BUL[x], 32000);
+      uni[64 + 2 * x] = (int16_t)sfd_min(F->BUL[x], 32000);                               // bulge[u], u = x
+      uni[64 + 2 * x + 1] = x >= 4 ? (int16_t)sfd_min(F->L1N[x - 1], 32000) : (int16_t)32767;  // 1xn of total size u
     }
   }
   // the rolling tables start out as "no structure": the guarded short-diagonal code reads rows no diagonal of the
@@ -954,9 +966,9 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
         const int um = d - 2 - (SFD_TURN + 1);
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-          const int e = (tid & 63) + 64 * h, t = e >> 5, idx = e & 31;
-          const int lim = um - (t == 0 ? 4 : (t == 2 ? 1 : 0));  // NIN[u-4], IL[u], L1N[u-1], BUL[u]
-          gt[e] = idx <= lim ? X.uNIN[e] : (int16_t)32767;
+          const int e = (tid & 63) + 64 * h;
+          const int u = e < 32 ? e + 4 : (e < 64 ? e - 32 : (e - 64) >> 1);  // NIN[u-4], IL[u], (BUL[u], L1N[u-1])
+          gt[e] = u <= um ? X.uNIN[e] : (int16_t)32767;
         }
         SF_WAVE_SYNC();
         uni = gt;
@@ -974,7 +986,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
         else if (!helper) sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_DML>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni);
         else {
           sf_fast_cell<false, WT, SF_SEC_HELP>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni);
-          if (valid) X.C1N[slotd * (W - 4) + i - 1] = (int16_t)sfd_min(eh, 32000);
+          if (valid) X.BN[2 * (slotd * (W - 4) + i - 1) + 1] = (int16_t)sfd_min(eh, 32000);
         }
       }
 #ifdef SF_STAMP
@@ -983,7 +995,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
       if (split) {
         __syncthreads();
         if (!helper && __ballot(valid)) {
-          if (valid) eh = X.C1N[slotd * (W - 4) + i - 1];
+          if (valid) eh = X.BN[2 * (slotd * (W - 4) + i - 1) + 1];
           sf_fast_cell<false, WT, SF_SEC_FIN>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni);
         }
       }

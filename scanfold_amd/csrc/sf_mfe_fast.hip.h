@@ -142,7 +142,7 @@ static inline __host__ __device__ SfFastLayout sf_fast_layout(int W) {
   L.off_ci = o; o += roll;   // the exterior pass reuses this area for f5[] and the mismatchExt table
   L.off_c1n = o; o += roll;
   L.off_cb = o; o += roll;
-  L.off_dml = o; o += ((4 * RW + 1) & ~1) * 2;
+  L.off_dml = o;  // (end of the rolling tables; the rolling rows of multiloop-split minima that used to follow are gone)
   L.off_tab = o; o += SF_FAST_TAB_BYTES;
   L.off_red = o;  // (unused)
   L.off_flag = o; o += 4;
@@ -208,7 +208,7 @@ template <bool G, int WT, int SEC>
 __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, const int i, const bool valid,
                                              const int slot2, const int slotd, uint32_t (&HP)[14], int &ovf,
                                              const bool final_fml, const int fnb, int &fpart, int &dec, int &eh, int &e0,
-                                             const int16_t *uni) {
+                                             const int16_t *uni, int &dprev) {
   // size tables [4][32]: asymmetry, loop initiation, 1xn, bulge (the kernel passes guarded copies on short diagonals)
   // third table: 32-bit pairs (bulge[u], 1xn term of total size u — 32767 for u < 4, where no 1xn loop exists)
   const int16_t *const uNIN = uni, *const uIL = uni + 32, *const uBN = uni + 64;
@@ -446,7 +446,7 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
       // multiloop closed by (i,j)
       {
         const int tr = sfd_rtype(type);
-        const int dml = X.DMLr[((d - 2) & 3) * RW + i0 + 1];
+        const int dml = dprev;  // multiloop split of (i+1, j-1): this thread's previous cell
         e = sfd_min(e, dml + X.tM[SF_TIDX(tr, sj1, si1)] + (tr > 2 ? TAU : 0) + X.MLintern + X.MLclosing);
       }
       e0 = e;
@@ -492,7 +492,7 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
   if (final_fml && d > SFD_TURN + 1) f = sfd_min(f, fnb);
   if ((SEC & SF_SEC_DML) && (SEC & SF_SEC_FIN)) multiloop_split();
   f = sfd_min(f, dec);
-  X.DMLr[(d & 3) * RW + i0] = (int16_t)(dec > SF_FAST_THRESH ? SF_INF16 : dec);
+  dprev = dec > SF_FAST_THRESH ? SF_INF16 : dec;
   fpart = f;
   if (final_fml && f < SF_FAST_OVF) ovf = 1;
   // final on the even diagonal; provisional (neighbour term still missing) on the odd one
@@ -874,7 +874,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
   X.CI = (int16_t *)(smem + Lo.off_ci);
   X.C1N = nullptr; X.CB = nullptr;
   X.BN = (int16_t *)(smem + Lo.off_c1n);  // spans the two areas
-  X.DMLr = (int16_t *)(smem + Lo.off_dml);
+  X.DMLr = nullptr;  // (the multiloop split of the enclosed cell is carried in a register: same thread, two diagonals earlier)
   int16_t *tab = (int16_t *)(smem + Lo.off_tab);
   // Pair types are 1..6, so only those rows of a [type][5][5] table exist here and the pointers are biased by
   // one row.  mismatch23 keeps its (zero) row 0: it is also indexed with the type of an enclosed cell that may
@@ -933,10 +933,10 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
     __syncthreads();
     for (int x = tid; x < W; x += NT) S[x + 1] = sf_encode_nt(src[x]);
     if (tid == 0) { S[0] = 0; S[W + 1] = 0; flag[0] = 0; }
-    for (int x = tid; x < 4 * RW; x += NT) X.DMLr[x] = SF_INF16;  // diagonals 2,3 have no multiloop split
     __syncthreads();
     int ovf = 0;
     uint32_t H[14];  // packed int16 pairs, see HGET/HSET
+    int dprev = SF_INF16;   // multiloop split of this thread's previous cell (diagonals 2, 3: none)
     int fnb = SF_FAST_BIG;  // even group: min of the two fML neighbours of the next cell, + MLbase
 #pragma unroll
     for (int k = 0; k < 14; k++) H[k] = (uint32_t)SF_INF16 | ((uint32_t)SF_INF16 << 16);
@@ -981,11 +981,11 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
 #else
       if (__ballot(valid)) {
 #endif
-        if (d0 < SF_FAST_TINY_D0) sf_fast_cell<true, WT, SF_SEC_ALL>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni);
-        else if (!split) sf_fast_cell<false, WT, SF_SEC_ALL>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni);
-        else if (!helper) sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_DML>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni);
+        if (d0 < SF_FAST_TINY_D0) sf_fast_cell<true, WT, SF_SEC_ALL>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev);
+        else if (!split) sf_fast_cell<false, WT, SF_SEC_ALL>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev);
+        else if (!helper) sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_DML>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev);
         else {
-          sf_fast_cell<false, WT, SF_SEC_HELP>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni);
+          sf_fast_cell<false, WT, SF_SEC_HELP>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev);
           if (valid) X.BN[2 * (slotd * (W - 4) + i - 1) + 1] = (int16_t)sfd_min(eh, 32000);
         }
       }
@@ -996,7 +996,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
         __syncthreads();
         if (!helper && __ballot(valid)) {
           if (valid) eh = X.BN[2 * (slotd * (W - 4) + i - 1) + 1];
-          sf_fast_cell<false, WT, SF_SEC_FIN>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni);
+          sf_fast_cell<false, WT, SF_SEC_FIN>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev);
         }
       }
 #ifdef SF_STAMP

@@ -204,7 +204,7 @@ struct SfFastCtx {
 //   SF_SEC_C0    hairpin and generic minima -> e0 (needs HP)
 //   SF_SEC_FIN   c = min(e0, eh, multiloop closing); publishes the cell (needs dec)
 enum { SF_SEC_P1 = 1, SF_SEC_HELP = 2, SF_SEC_DML = 4, SF_SEC_FIN = 8, SF_SEC_C0 = 16, SF_SEC_ALL = 31 };
-template <bool G, int WT, int SEC>
+template <bool G, int WT, int SEC, bool CH = false>
 __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, const int i, const bool valid,
                                              const int slot2, const int slotd, uint32_t (&HP)[14], int &ovf,
                                              const bool final_fml, const int fnb, int &fpart, int &dec, int &eh, int &e0,
@@ -224,6 +224,9 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
   const int j = i + d, i0 = i - 1;
   const uint8_t *S = X.S;
   const int umax = G ? sfd_min(SFD_MAXLOOP, d - 2 - (SFD_TURN + 1)) : SFD_MAXLOOP;
+  // CH (short diagonals, 12 <= d < 36, straight-line code with guarded size tables): whole batches of sizes above
+  // the wave-uniform limit are skipped — the kernel is close to VALU-bound, work on sizes that cannot exist is not free
+  const int um = CH ? d - 2 - (SFD_TURN + 1) : SFD_MAXLOOP;
   const int type = d <= X.maxd ? X.tPair[S[i] * 8 + S[j]] : 0;  // max_bp_span: longer pairs do not exist
   const int si1 = S[i + 1], sj1 = S[j - 1];
 // fML triangle without diagonals 0..3: base(d) = sum_{k=4}^{d-1} (W-k)
@@ -250,13 +253,14 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
     // min / saturating add / min (v_pk_*_i16): the four candidates are packed pairwise (one v_perm each), the
     // asymmetry terms of both sizes are one aligned 32-bit read of the int16 table.  Descending order, so
     // HP[p-1] still holds the enclosed cell's minima.  Size 30 (x = 26) has no partner.
-    {
+    if (!CH || um >= 30) {
       const int16_t *row = X.CI + ROW(30) + i0;
       const int e = sfd_min(row[3], row[29]) + SF_UNI(uNIN, 26);
       HSET(26, sfd_min(e, HGET(24)));
     }
 #pragma unroll
     for (int pb = 12; pb >= 1; pb -= 3) {  // batches of three pairs = 12 candidate reads + 3 term reads in flight
+      if (CH && um < 2 * pb) continue;     // sizes 2pb .. 2pb+5; skipped registers keep "none" (never written so far)
       uint32_t e1[3], e2[3], nn[3];
 #pragma unroll
       for (int k = 0; k < 3; k++) {
@@ -347,6 +351,7 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
         uint32_t acc = sf_pk(32767, 32767);
 #pragma unroll
         for (int ub = 2; ub <= 30; ub += 2) {
+          if (CH && ub > um) continue;
           uint32_t w0[2], w1[2], w2[2], w3[2], wt[2];
 #pragma unroll
           for (int k = 0; k < 2; k++) {
@@ -437,7 +442,8 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
           // half of HP[13] stays INF)
           uint32_t ggp = sf_pk(32767, 32767);
 #pragma unroll
-          for (int pp = 1; pp <= 13; pp++) ggp = sf_pkmin(ggp, sf_pkadd(HP[pp], sf_ldw(uIL + 2 * pp + 4)));
+          for (int pp = 1; pp <= 13; pp++)
+            if (!CH || um >= 2 * pp + 4) ggp = sf_pkmin(ggp, sf_pkadd(HP[pp], sf_ldw(uIL + 2 * pp + 4)));
           gg = sfd_min(sf_lo(ggp), sf_hi(ggp));
         }
 #endif
@@ -982,6 +988,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
       if (__ballot(valid)) {
 #endif
         if (d0 < SF_FAST_TINY_D0) sf_fast_cell<true, WT, SF_SEC_ALL>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev);
+        else if (d0 < SFD_MAXLOOP + 6) sf_fast_cell<false, WT, SF_SEC_ALL, true>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev);
         else if (!split) sf_fast_cell<false, WT, SF_SEC_ALL>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev);
         else if (!helper) sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_DML>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev);
         else {

@@ -62,8 +62,26 @@ __host__ __device__ inline size_t sf_pfl_lds_bytes(int W) {
   return dbl * sizeof(double) + 2 * (size_t)(W + 2) * sizeof(int) + (size_t)(W + 8) + 64;
 }
 static inline bool sf_pfl_supported(int W) {
-  return W >= 16 && 2 * W - 4 < 2 * SF_PFL_SLOTS && sf_pfl_lds_bytes(W) <= SF_PFL_LDS_LIMIT;
+  return W >= 16 && W <= 128 && 2 * W - 4 < 2 * SF_PFL_SLOTS && sf_pfl_lds_bytes(W) <= SF_PFL_LDS_LIMIT;  // (exterior sweeps: two columns per lane)
 }
+
+// v of lane l (l wave-uniform), 64-bit
+__device__ __forceinline__ double sf_lane_read_f64(const double v, const int l) {
+#ifdef SF_EMUL
+  return __shfl(v, l);
+#else
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b & 0xffffffffu), l);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+#endif
+}
+
+#ifdef SF_STAMP
+// diagnostic build only: cycles of block 0 in inside / exterior / outside / the rest of a fold, and the fold count
+__device__ unsigned long long sf_pf_stamp_acc[8];
+#define SF_PFT() __builtin_amdgcn_s_memtime()
+#endif
 
 template <int WT>
 __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__restrict__ seqs, int n, int row_stride,
@@ -145,6 +163,9 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
     }
     __syncthreads();
 
+#ifdef SF_STAMP
+    const unsigned long long ts0 = SF_PFT();
+#endif
     // ================= inside: columns j ascending =================
     double H[27];
 #pragma unroll
@@ -325,31 +346,82 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
       __syncthreads();
     }
 
+#ifdef SF_STAMP
+    const unsigned long long ts1 = SF_PFT();
+#endif
     // ================= exterior =================
-    if (tid == 0) { q5[0] = 1.0; q3[W + 1] = 1.0; }
+    // q5[j] = q5[j-1] + sum_i q5[i-1] qb[i,j] ExtLoop(i,j) and its mirror image q3, each by ONE wave as a sweep
+    // without any reduction across lanes (the block-wide sum + barrier per column this replaces took 15 % of a
+    // fold): wave 0 walks the rows i upwards with a lane per column j, P[j] += q5[i-1] qb[i,j] w(i,j), where
+    // q5[i-1] = q5[i-2] + P[i-1] is final by then (column i-1 only has rows <= i-5) and comes from its lane by
+    // v_readlane; wave 1 walks the columns downwards with a lane per row, q3[j+1] from the lane of row j+1.
+    // w(i,j) from a 30 x 30 table over (S[j], S[j+1] or "none") x (S[i], S[i-1] or "none"), built in the FAC area
+    // (its inside-orientation tables are dead, the outside ones are built after this).
+    for (int e = tid; e < 900; e += SF_PFL_NT) {
+      const int cf = e / 30, cb = e - cf * 30;
+      const int sj = cf / 6, s3 = cf - sj * 6, si = cb / 6, s5 = cb - si * 6;
+      const int t = (si < 5 && sj < 5) ? D->pair[si][sj] : 0;
+      FAC[e] = t ? sfx_extloop(X, t, s5 < 5 ? s5 : -1, s3 < 5 ? s3 : -1) : 0.0;
+    }
     __syncthreads();
-    for (int j = 1; j <= W; j++) {
-      double val = 0.0;
-      const int i = tid + 1;
-      if (i + SFD_TURN + 1 <= j) {
-        const int type = OWN(i, j);
-        if (type) val = q5[i - 1] * QBC(i, j) * sfx_extloop(X, type, i > 1 ? S[i - 1] : -1, j < W ? S[j + 1] : -1);
+    if (tid < 128) {
+      constexpr int NQ = 2;  // sf_pfl_supported: W <= 128
+      const int lane = tid & 63;
+      const bool fwd = tid < 64;
+      double P[NQ];
+      int code[NQ];  // this lane's columns (forward) / rows (backward): table row / entry
+#pragma unroll
+      for (int q = 0; q < NQ; q++) {
+        const int x = lane + 64 * q + 1;
+        P[q] = 0.0;
+        if (x > W) code[q] = 0;
+        else if (fwd) code[q] = (S[x] * 6 + (x < W ? S[x + 1] : 5)) * 30;
+        else code[q] = S[x] * 6 + (x > 1 ? S[x - 1] : 5);
       }
-      val = sf_block_sum(val, red);
-      if (tid == 0) q5[j] = q5[j - 1] + val;
-      __syncthreads();
-    }
-    for (int i = W; i >= 1; i--) {
-      double val = 0.0;
-      const int j = tid + 1;
-      if (j <= W && i + SFD_TURN + 1 <= j) {
-        const int type = OWN(i, j);
-        if (type) val = QBC(i, j) * sfx_extloop(X, type, i > 1 ? S[i - 1] : -1, j < W ? S[j + 1] : -1) * q3[j + 1];
+      auto owner_sum = [&](const int x) -> double {  // P of column / row x, from the lane that owns it
+        const int l = (x - 1) & 63, q = (x - 1) >> 6;
+        const double v0 = sf_lane_read_f64(P[0], l), v1 = sf_lane_read_f64(P[1], l);
+        return q ? v1 : v0;
+      };
+      if (fwd) {
+        double qprev = 1.0;  // q5[i-1] while row i is processed
+        if (lane == 0) q5[0] = 1.0;
+        for (int i = 1; i <= W; i++) {
+          if (i >= 2) {
+            qprev += owner_sum(i - 1);
+            if (lane == 0) q5[i - 1] = qprev;
+          }
+          if (i > W - SFD_TURN - 1) continue;
+          const int cb = S[i] * 6 + (i > 1 ? S[i - 1] : 5);
+#pragma unroll
+          for (int q = 0; q < NQ; q++) {
+            const int j = lane + 64 * q + 1;
+            if (j <= W && i + SFD_TURN + 1 <= j && j - i <= maxd) P[q] += qprev * QBC(i, j) * FAC[code[q] + cb];
+          }
+        }
+        qprev += owner_sum(W);
+        if (lane == 0) q5[W] = qprev;
+      } else {
+        double qnext = 1.0;  // q3[j+1] while column j is processed
+        if (lane == 0) q3[W + 1] = 1.0;
+        for (int j = W; j >= 1; j--) {
+          if (j < W) {
+            qnext += owner_sum(j + 1);
+            if (lane == 0) q3[j + 1] = qnext;
+          }
+          if (j < SFD_TURN + 2) continue;
+          const int cf = (S[j] * 6 + (j < W ? S[j + 1] : 5)) * 30;
+#pragma unroll
+          for (int q = 0; q < NQ; q++) {
+            const int i = lane + 64 * q + 1;
+            if (i + SFD_TURN + 1 <= j && j - i <= maxd) P[q] += QBC(i, j) * FAC[cf + code[q]] * qnext;
+          }
+        }
+        qnext += owner_sum(1);
+        if (lane == 0) q3[1] = qnext;
       }
-      val = sf_block_sum(val, red);
-      if (tid == 0) q3[i] = q3[i + 1] + val;
-      __syncthreads();
     }
+    __syncthreads();
     const double Z = q5[W];
     if (centroid)
       for (int x = tid; x <= W; x += SF_PFL_NT) centroid[(size_t)fold * W1 + x] = (x < W) ? '.' : 0;
@@ -365,6 +437,9 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
     }
     __syncthreads();
 
+#ifdef SF_STAMP
+    const unsigned long long ts2 = SF_PFT();
+#endif
     // ================= outside: columns l descending =================
 #pragma unroll
     for (int u = 0; u < 27; u++) H[u] = 0.0;
@@ -559,6 +634,12 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
       }
       __syncthreads();
     }
+#ifdef SF_STAMP
+    if (blockIdx.x == 0 && tid == 0) {
+      const unsigned long long ts3 = SF_PFT();
+      sf_pf_stamp_acc[0] += ts1 - ts0; sf_pf_stamp_acc[1] += ts2 - ts1; sf_pf_stamp_acc[2] += ts3 - ts2; sf_pf_stamp_acc[3] += 1;
+    }
+#endif
     mbd = sf_block_sum(mbd, red);
     __syncthreads();
     cd = sf_block_sum(cd, red);

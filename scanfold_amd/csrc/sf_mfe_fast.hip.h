@@ -874,7 +874,6 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
   const int W = WT ? WT : Wrt;
   SF_DYN_SMEM(smem);
   const SfFastLayout Lo = sf_fast_layout(W);
-  const int RW = W - 4;
   SfFastCtx X;
   X.fML = (int16_t *)smem;
   X.CI = (int16_t *)(smem + Lo.off_ci);

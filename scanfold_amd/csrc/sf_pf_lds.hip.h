@@ -58,7 +58,7 @@
 
 __host__ __device__ inline size_t sf_pfl_lds_bytes(int W) {
   const size_t NC = (size_t)(W - 4) * (W - 3) / 2, RP = W + 2 * SF_PFL_PAD, VW = W + 8;
-  const size_t dbl = 2 * NC + 12 * RP + 3 * 625 + 2 * VW + 8 + 6 * VW + 5 * VW + (W + 2) + (W + 3) + 16 + 4 * 32 + (W + 8);
+  const size_t dbl = 2 * NC + 12 * RP + 3 * 625 + 2 * VW + 8 + 6 * VW + 7 * VW + (W + 2) + (W + 3) + 16 + 4 * 32 + (W + 8);
   return dbl * sizeof(double) + 2 * (size_t)(W + 2) * sizeof(int) + (size_t)(W + 8) + 64;
 }
 static inline bool sf_pfl_supported(int W) {
@@ -79,7 +79,7 @@ __device__ __forceinline__ double sf_lane_read_f64(const double v, const int l) 
 
 #ifdef SF_STAMP
 // diagnostic build only: cycles of block 0 in inside / exterior / outside / the rest of a fold, and the fold count
-__device__ unsigned long long sf_pf_stamp_acc[8];
+__device__ unsigned long long sf_pf_stamp_acc[32];  // [0..2] phases, [3] folds, [8+team] / [16+team] work before the first barrier of an inside / outside column, [20] / [21] team 2 between the two barriers
 #define SF_PFT() __builtin_amdgcn_s_memtime()
 #endif
 
@@ -104,8 +104,8 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
   double *FAC = DER + 12 * RP;    // [3][25][25] family-A weights
   double *QM1 = FAC + 3 * 625;    // [2][VW]
   double *RV = QM1 + 2 * VW + 8;  // R0[2], R1[2], R01[2], each VW, row r at r + 8 (rows <= 0 stay 0)
-  double *ZP = RV + 6 * VW;       // [4 teams][VW] partial sums of the current column, [4] = team 1's half of qm / R1
-  double *q5 = ZP + 5 * VW;       // [W+2]
+  double *ZP = RV + 6 * VW;       // [4 teams][VW] partial sums of the current column, [4..6] = the three parts of qm / R1
+  double *q5 = ZP + 7 * VW;       // [W+2]
   double *q3 = q5 + (W + 2);      // [W+3]
   double *red = q3 + (W + 3);     // [16]
   double *WN = red + 16;          // ninio[32]
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
     for (int x = tid; x < W; x += SF_PFL_NT) S[x + 1] = sf_encode_nt(src[x]);
     if (tid == 0) { S[0] = 0; S[W + 1] = 0; }
     for (int x = tid; x < 12 * RP; x += SF_PFL_NT) DER[x] = 0.0;
-    for (int x = tid; x < 13 * VW + 8; x += SF_PFL_NT) QM1[x] = 0.0;  // QM1, the six R vectors, the partial sums
+    for (int x = tid; x < 15 * VW + 8; x += SF_PFL_NT) QM1[x] = 0.0;  // QM1, the six R vectors, the partial sums
     __syncthreads();
     for (int x = tid; x <= W + 1; x += SF_PFL_NT) {
       const int cf = S[x] * 5 + (x <= W ? S[x + 1] : 0), cb = S[x] * 5 + (x >= 1 ? S[x - 1] : 0);
@@ -171,6 +171,9 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
 #pragma unroll
     for (int u = 0; u < 27; u++) H[u] = 0.0;
     for (int j = SFD_TURN + 2; j <= W + 1; j++) {
+#ifdef SF_STAMP
+      const unsigned long long tc0 = SF_PFT();
+#endif
       // j = W+1 only finishes qm of column W
       const int s = (j <= c - 1) ? c : c + SF_PFL_SLOTS;
       const int i = s - j, d = j - i;
@@ -182,18 +185,19 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
       const int umax = sfd_min(SFD_MAXLOOP, d - 2 - (SFD_TURN + 1));
       // qm of column j-1, row i:  qm[i,j-1] = sum_{a>=0} MLbase^a qm1[i+a,j-1] + sum_{a>=5} qm[i,i+a-1] qm1[i+a,j-1].
       // The a >= 5 part runs in blocks of eight terms; team 1 takes the first half of the blocks (plus the
-      // a < 5 terms), team 2 the rest; the overshoot of the last block reads rows > j-5 of qm1, which are 0.
+      // a < 5 terms), team 0 — the lightest here, tools/gpu_pf_stamp.py — the rest (a share for team 3 was measured
+      // slower: its own multiloop sum grows with the same columns); the overshoot of the last block reads rows > j-5 of qm1, which are 0.
       const int dq = j - 1 - i;
       const bool qvalid = (i >= 1) && (dq >= SFD_TURN + 1);
-      auto qm_part = [&](const int half) -> double {
+      auto qm_part = [&](const int part) -> double {
         const int amax = dq - SFD_TURN - 1;
-        const int nb = (amax - 4 + 7) >> 3, nb1 = nb >> 1;  // blocks of eight terms starting at a = 5
+        const int nb = (amax - 4 + 7) >> 3, nbh = nb >> 1;  // blocks of eight terms starting at a = 5
         double m = 0.0, m2 = 0.0;
-        if (half == 0) {
+        if (part == 0) {
           m = qm1p[i];
           for (int a = 1; a <= sfd_min(amax, 4); a++) m += MLB[a] * qm1p[i + a];
         }
-        const int b0 = half ? nb1 : 0, b1 = half ? nb : nb1;
+        const int b0 = part ? nbh : 0, b1 = part ? nb : nbh;
         const int a0 = 5 + 8 * b0;
         const double *qmr = QM + i - 1, *q1 = qm1p + i;
         int off = DOFF(a0 - 1), st = W - (a0 - 1);  // DOFF(a-1) and its increment
@@ -211,7 +215,7 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
         }
         return m + m2;
       };
-      double qm_half = 0.0;  // team 2's half of qm[i,j-1], completed after the barrier
+      double wml = 0.0;      // team 2: multiloop-stem weight of (i,j), fetched from device memory ahead of its use after the barrier
       if (team == 0) {
         if (valid) {
           const int type = OWN(i, j);
@@ -269,6 +273,7 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
           }
           ZP[i] = z;
         }
+        if (qvalid) ZP[5 * VW + i] = qm_part(1);
       } else if (team == 1) {
         if (valid) {
           const int type = OWN(i, j);
@@ -287,10 +292,11 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
         }
         if (qvalid) ZP[4 * VW + i] = qm_part(0);
       } else if (team == 2) {
-        if (qvalid) qm_half = qm_part(1);
         if (valid) {
           const int type = OWN(i, j);
-          const int si1 = S[i + 1], sj1 = S[j - 1];
+          if (type) wml = sfx_mlstem(X, type, i > 1 ? S[i - 1] : -1, j < W ? S[j + 1] : -1);
+        }
+        if (valid) {
           const double *d1N2 = DERP(1, j - 2) + i;
           const double *f1N = FAC + 625 + SF_PK_CODE(BWD[i + 2]);
           const double *qbA = QB + i + 1;  // row i+2
@@ -301,7 +307,8 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
             const double t = ((u <= umax ? an : 0.0) + d1N2[u]) * WIL1N[u];
             if (u & 1) g2 += t; else g1 += t;
           }
-          ZP[2 * VW + i] = (g1 + g2) * X->mismatch1nI[type][si1][sj1];
+          // mismatch1nI[type][S[i+1]][S[j-1]]: the family-A table read with the roles of row and column swapped
+          ZP[2 * VW + i] = (g1 + g2) * FAC[625 + SF_PK_ROW(FWD[i]) + SF_PK_CODE(BWD[j])];
         }
       } else {
         if (valid) {
@@ -328,21 +335,30 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
                            (type ? sfx_hairpin(D, X, S, i, j, type) : 0.0);
         }
       }
+#ifdef SF_STAMP
+      if (blockIdx.x == 0 && (tid & 127) == 0) sf_pf_stamp_acc[8 + team] += SF_PFT() - tc0;
+#endif
       __syncthreads();
-      if (team == 2 && qvalid) QMD(dq, i) = qm_half + ZP[4 * VW + i];
+#ifdef SF_STAMP
+      const unsigned long long tc1 = SF_PFT();
+#endif
+      if (team == 2 && qvalid) QMD(dq, i) = ZP[5 * VW + i] + ZP[4 * VW + i];
       if (team == 2 && valid) {
         const int type = OWN(i, j);
         const int tr = sfd_rtype(type);
-        const int sp1 = S[i - 1], sq1 = S[j + 1];
         const double qbij = type ? (ZP[i] + ZP[VW + i]) + (ZP[2 * VW + i] + ZP[3 * VW + i]) : 0.0;
         QBC(i, j) = qbij;
-        DERP(0, j)[i] = type ? qbij * X->mismatchI[tr][sq1][sp1] : 0.0;
-        DERP(1, j)[i] = type ? qbij * X->mismatch1nI[tr][sq1][sp1] : 0.0;
+        const int fa = SF_PK_ROW(FWD[j]) + SF_PK_CODE(BWD[i]);  // (S[j], S[j+1]) x (S[i], S[i-1]): LDS, not device memory
+        DERP(0, j)[i] = type ? qbij * FAC[fa] : 0.0;
+        DERP(1, j)[i] = type ? qbij * FAC[625 + fa] : 0.0;
         DERP(2, j)[i] = (type && tr > 2) ? qbij * xTAU : qbij;
         double m1 = qm1p[i] * xMLbase;
-        if (type) m1 += qbij * sfx_mlstem(X, type, i > 1 ? sp1 : -1, j < W ? sq1 : -1);
+        if (type) m1 += qbij * wml;
         qm1c[i] = m1;
       }
+#ifdef SF_STAMP
+      if (blockIdx.x == 0 && tid == 256) sf_pf_stamp_acc[20] += SF_PFT() - tc1;
+#endif
       __syncthreads();
     }
 
@@ -445,6 +461,9 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
     for (int u = 0; u < 27; u++) H[u] = 0.0;
     double mbd = 0.0, cd = 0.0;
     for (int l = W; l >= SFD_TURN + 2; l--) {
+#ifdef SF_STAMP
+      const unsigned long long tc0 = SF_PFT();
+#endif
       const int s = (l <= c - 1) ? c : c + SF_PFL_SLOTS;
       const int k = s - l, d = l - k;
       const bool valid = (k >= 1) && (d >= SFD_TURN + 1);
@@ -456,13 +475,14 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
       SF_LANE_TABLE(tcol, L, COFF(sfd_min(l + L, W)));
       const bool r3 = k - 3 >= 1, r2 = k - 2 >= 1;  // the row exists
       // R1 of the next column l-1, row k: closers (k, m), m >= l+5, right part qm[l, m-1]; the range of m is the
-      // same for every row: team 1 takes its first half, team 2 the rest
-      auto r1_part = [&](const int half) -> double {
+      // same for every row: team 1 takes its first half, teams 3 and 2 a quarter each (shares from the measured load of the teams)
+      auto r1_part = [&](const int part) -> double {
         double r1 = 0.0, r1b = 0.0;
         const double *fW = FAC + 1250 + SF_PK_CODE(FWD[k]);
-        const int mlo = l + SFD_TURN + 2, mmid = mlo + ((sfd_max(W + 1 - mlo, 0) >> 1) & ~3);
-        int m = half ? mmid : mlo;
-        const int mhi = half ? W : mmid - 1;
+        const int mlo = l + SFD_TURN + 2, len = sfd_max(W + 1 - mlo, 0);
+        const int mmid = mlo + ((len >> 1) & ~3), m3q = mmid + ((sfd_max(W + 1 - mmid, 0) >> 1) & ~3);
+        int m = part == 0 ? mlo : (part == 1 ? mmid : m3q);
+        const int mhi = part == 0 ? mmid - 1 : (part == 1 ? m3q - 1 : W);
         for (; m + 3 <= mhi; m += 4) {
           r1 += QBC(k, m) * fW[SF_PK_ROW(BWD[m])] * QMD(m - 1 - l, l) +
                 QBC(k, m + 2) * fW[SF_PK_ROW(BWD[m + 2])] * QMD(m + 1 - l, l);
@@ -472,7 +492,6 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
         for (; m <= mhi; m++) r1 += QBC(k, m) * fW[SF_PK_ROW(BWD[m])] * QMD(m - 1 - l, l);
         return r1 + r1b;
       };
-      double r1_half = 0.0;  // team 2's half of R1[k], completed after the barrier
       if (team == 0) {
         if (valid) {
           const double *dI3 = DERP(0, l + 3) + k;
@@ -561,10 +580,10 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
         }
       } else if (team == 2) {
         if (valid) {
-          r1_half = r1_part(1);
           const int type = OWN(k, l);
           const int rt = sfd_rtype(type);
           const int sp1 = S[k - 1], sq1 = S[l + 1];
+          const double w1n = X->mismatch1nI[rt][sq1][sp1];  // device memory: issued before the long sums below
           const double *d1N2 = DERP(1, l + 2) + k;
           const bool c2 = l + 2 <= W;
           const int kr2 = r2 ? k - 2 : 1;
@@ -579,7 +598,8 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
             const double t = (n1 + n2) * WIL1N[u];
             if (u & 1) g2 += t; else g1 += t;
           }
-          ZP[2 * VW + k] = (g1 + g2) * X->mismatch1nI[rt][sq1][sp1];
+          ZP[2 * VW + k] = (g1 + g2) * w1n;
+          ZP[6 * VW + k] = r1_part(2);
         }
       } else {
         if (valid) {
@@ -606,22 +626,29 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
             }
           }
           ZP[3 * VW + k] = (ms + ms2) * sfx_mlstem(X, type, sp1, sq1);
+          ZP[5 * VW + k] = r1_part(1);
         }
       }
+#ifdef SF_STAMP
+      if (blockIdx.x == 0 && (tid & 127) == 0) sf_pf_stamp_acc[16 + team] += SF_PFT() - tc0;
+#endif
       __syncthreads();
+#ifdef SF_STAMP
+      const unsigned long long tc1 = SF_PFT();
+#endif
       if (team == 2 && valid) {
         const int type = OWN(k, l);
-        const int si1 = S[k + 1], sj1 = S[l - 1];
         const double qbkl = QBC(k, l);
         double o = 0.0;
         if (type && qbkl != 0.0) o = inner ? (ZP[k] + ZP[VW + k]) + (ZP[2 * VW + k] + ZP[3 * VW + k]) : ZP[k];
         QBC(k, l) = o;
-        DERP(0, l)[k] = type ? o * X->mismatchI[type][si1][sj1] : 0.0;
-        DERP(1, l)[k] = type ? o * X->mismatch1nI[type][si1][sj1] : 0.0;
+        const int fa = SF_PK_ROW(BWD[l]) + SF_PK_CODE(FWD[k]);  // (S[l], S[l-1]) x (S[k], S[k+1]): LDS, not device memory
+        DERP(0, l)[k] = type ? o * FAC[fa] : 0.0;
+        DERP(1, l)[k] = type ? o * FAC[625 + fa] : 0.0;
         DERP(2, l)[k] = (type > 2) ? o * xTAU : o;
-        const double w = type ? o * X->MLclosing * sfx_mlstem(X, sfd_rtype(type), sj1, si1) : 0.0;
+        const double w = type ? o * FAC[1250 + fa] : 0.0;
         const double r0 = w + xMLbase * R0c[k];
-        const double r1 = r1_half + ZP[4 * VW + k];
+        const double r1 = (ZP[5 * VW + k] + ZP[6 * VW + k]) + ZP[4 * VW + k];
         R0n[k] = r0;
         R1n[k] = r1;
         R01n[k] = r0 + r1;
@@ -632,6 +659,9 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
           if (centroid) { centroid[(size_t)fold * W1 + k - 1] = '('; centroid[(size_t)fold * W1 + l - 1] = ')'; }
         } else cd += p;
       }
+#ifdef SF_STAMP
+      if (blockIdx.x == 0 && tid == 256) sf_pf_stamp_acc[21] += SF_PFT() - tc1;
+#endif
       __syncthreads();
     }
 #ifdef SF_STAMP

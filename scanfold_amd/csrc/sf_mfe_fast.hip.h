@@ -47,6 +47,9 @@
 #endif
 // even diagonals below this one run the size-tested cell code (some special loops do not exist yet: d <= 11)
 #define SF_FAST_TINY_D0 12
+// even diagonals below this one skip whole batches of loop sizes above the limit (CH); from here to 36 the skipped
+// work is small and the unbroken straight-line code is faster (measured: 20 / 24 / 28 / 36 -> 87.5 / 87.1 / 87.0 / 87.9 ms)
+#define SF_FAST_CHUNK_D0 28
 #ifndef SF_FAST_SPLIT
 #define SF_FAST_SPLIT 1  // long diagonals: the idle second wave of a group takes part of the cell's work
 #endif
@@ -987,7 +990,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
       if (__ballot(valid)) {
 #endif
         if (d0 < SF_FAST_TINY_D0) sf_fast_cell<true, WT, SF_SEC_ALL>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev);
-        else if (d0 < SFD_MAXLOOP + 6) sf_fast_cell<false, WT, SF_SEC_ALL, true>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev);
+        else if (d0 < SF_FAST_CHUNK_D0) sf_fast_cell<false, WT, SF_SEC_ALL, true>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev);
         else if (!split) sf_fast_cell<false, WT, SF_SEC_ALL>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev);
         else if (!helper) sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_DML>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev);
         else {

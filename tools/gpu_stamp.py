@@ -7,7 +7,7 @@ _lib._share_hip_runtime_with_torch()
 eng = _lib.Engine(0, lib_path=os.path.join(ROOT, "tools", "stamp.so"))
 arr = np.frombuffer(b"ACGU", dtype=np.uint8)[np.random.default_rng(0).integers(0, 4, (65536, 120))]
 eng.mfe_batch(arr)
-out = (ctypes.c_ulonglong * 192)()
+out = (ctypes.c_ulonglong * 224)()
 eng.lib.sf_debug_stamps.argtypes = [ctypes.c_void_p]
 eng.lib.sf_debug_stamps(out)
 a = np.array(list(out)[:64], dtype=np.float64).reshape(8, 8)

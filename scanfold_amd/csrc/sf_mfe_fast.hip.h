@@ -3,20 +3,22 @@
 // Replaces energies(seq_list) -> rna_folder -> RNA.fold(seq) (ScanFold-Scan.py:244-246,253-262;
 // ScanFoldFunctions.py:774-789,805-814): r+1 folds per window whose structures the caller throws away.
 //
-// One workgroup folds one sequence at a time (persistent grid, sequences dealt round-robin); one barrier
-// per anti-diagonal d.  Thread mapping: a thread owns a CENTRE s = i+j (two centres, one per parity of d):
+// One workgroup folds one sequence at a time (persistent grid, sequences dealt round-robin); two anti-diagonals
+// per step (two thread groups), one barrier per step (two on the long diagonals).  Thread mapping: a thread owns a CENTRE s = i+j (two centres, one per parity of d):
 // on diagonal d it handles the cell i = v - d/2, j = i+d with v = (tid+OFF) mod NT.  The cell of the same
 // thread two diagonals later is (i-1, j+1), the cell that encloses it — which makes the interior-loop search
 // incremental (below) with all of its state in registers.
 //
-// LDS per workgroup (W=120: 40.6 kB -> 4 workgroups per CU):
+// LDS per workgroup (W=120: 39.8 kB -> 4 workgroups per CU):
 //   fML   int16 full triangle, diagonal-major          (the O(W^3) multiloop split reads every diagonal)
 //   CI, C1N, CB  int16, rolling window of SF_FAST_NR diagonals of c, pre-added with the inner pair's terms:
 //           CI  = c + mismatchI [rtype][S[j+1]][S[i-1]]   generic loops
 //           C1N = c + mismatch1nI[rtype][S[j+1]][S[i-1]]  1 x n loops
 //           CB  = c + TerminalAU(rtype)                   bulges (and, minus that term, the few special loops)
-//   DML   rolling 3 diagonals of min_k fML[i,k]+fML[k+1,j]
-//   small int16 parameter tables (mismatches, stack, dangles, pair types)
+//           (this kernel interleaves CB and C1N as one 32-bit word per cell, SfFastCtx::BN)
+//   small int16 parameter tables (mismatches — rows of the six pair types only —, stack, dangles, pair types)
+//   (min_k fML[i,k]+fML[k+1,j] of the enclosed cell, needed by the multiloop closing term, is the thread's own
+//   previous result: a register)
 //
 // Interior loops.  Of the 496 (u1,u2) candidates of a cell, 375 are "generic" (both sides >= 2, not 2x2/2x3):
 //   E = CI[p,q] + internal_loop[u1+u2] + min(max_ninio, ninio*|u1-u2|) + mismatchI[type][S[i+1]][S[j-1]].
@@ -26,9 +28,9 @@
 // H[i,j,u] = min(H[i+1,j-1,u-2], the two edge candidates u1=2 and u2=2): 2 LDS reads per u instead of u-3,
 // exact (same minimum over the same set).  H lives in registers because (i+1,j-1) is the same thread's
 // previous cell.  Bulges (2 per size), 1 x n loops (2 per size) and the 9 special candidates are direct.
-// Size-dependent terms are wave-uniform and come from scalar registers.
+// Size-dependent terms are wave-uniform reads of small LDS tables (per-wave guarded copies on short diagonals).
 //
-// c itself is streamed to a device scratch table (int16, coalesced) for the exterior-loop pass at the end.
+// c + ExtLoop is streamed to a device scratch table (int16, L2-resident) for the exterior-loop sweep at the end.
 //
 // int16 is exact while |energy| < 12000 dcal/mol; a fold that leaves that range (a >120 kcal/mol helix) is
 // appended to an overflow list and redone by the int32 kernel (sf_mfe_full.hip.h), so results never depend

@@ -83,7 +83,10 @@ def main():
             raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # SCANFOLD_BENCH_FORCE_DIST=1 (under torch.distributed.run --nproc-per-node 1): take the RCCL path with a single
+    # rank, to check process-group set-up, record packing and the all-gather on a one-GPU box
+    use_dist = world > 1 or os.environ.get("SCANFOLD_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         dist.init_process_group("nccl", device_id=dev)
     eng = _lib.Engine(device=local_rank)
 
@@ -107,13 +110,13 @@ def main():
         st = torch.cuda.current_stream().cuda_stream
         eng.scan_dev(tr.data_ptr(), len(seq), W, step, lo, n_loc, r, kind, wl["shuffle_seed"], 0, en.data_ptr(),
                      db.data_ptr(), cen.data_ptr(), div.data_ptr(), dG.data_ptr(), st)
-        if world > 1:
+        if use_dist:
             rec = sdist.pack_records(torch, W, r, en[:n_loc], db[:n_loc], cen[:n_loc], div[:n_loc], dG[:n_loc], n_pad)
             return sdist.gather_records(rec, world)
         return None
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -126,7 +129,7 @@ def main():
         step_fn()
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -167,7 +170,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(eng, seq, W, step, r, kind, wl["shuffle_seed"])
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -41,7 +41,7 @@ struct Ctx {
   SfDevParamsPF *dX = nullptr;
   SfFastParams *dF = nullptr;
   double temperature = 37.0;
-  DevBuf full_scratch, pf_scratch, fast_scratch, seqs, energies, db, cen, dbl, status, transcript, ovf;
+  DevBuf full_scratch, pf_scratch, pf_share, fast_scratch, seqs, energies, db, cen, dbl, status, transcript, ovf;
   std::string last_hip_error;
   // profiling of the dominant kernel
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
@@ -55,6 +55,8 @@ struct Ctx {
   int max_bp_span = 0;  // RNA.md().max_bp_span; <= 0: no limit
   int pf_kernel = 0;  // 0: LDS-resident kernel where it fits; 1: device-memory tables (SCANFOLD_PF_KERNEL=global)
   int pf_blocks_per_cu = 4;  // 256 VGPRs per thread: 2 waves per SIMD
+  int pf_run_len = 0;        // > 0: forced run length of the shared-inside mode
+  int pf_share_inside = 1;   // sf_scan, step 1: consecutive native windows share their inside tables (SCANFOLD_PF_SHARE=0: off)
 } g;
 
 #define HIPCHK(call)                                                              \
@@ -183,15 +185,35 @@ int launch_full(const uint8_t *d_seqs, const int *d_idx, const int *d_count, int
   return SF_OK;
 }
 
+// d_tr != null: the n rows are the native windows of transcript d_tr (length L) that start at win0, win0+1, ...
+// (sf_scan with step 1): consecutive windows share their inside tables (sf_pf_lds.hip.h).
 int launch_pf(const uint8_t *d_seqs, int n, int row_stride, int W, double *d_dG, double *d_mbd, char *d_cen,
-              double *d_cd, hipStream_t st) {
+              double *d_cd, hipStream_t st, const uint8_t *d_tr = nullptr, int L = 0, int win0 = 0) {
   if (n <= 0) return SF_OK;
   int grid = n < max_resident_blocks() ? n : max_resident_blocks();
   if (sf_pfl_supported(W) && !g.force_full && g.pf_kernel == 0) {
     // every table of a fold in the LDS of one CU: one workgroup per CU
     grid = n < g.n_cu ? n : g.n_cu;
+    int run_len = 1;
+    double *share = nullptr;
+    if (d_tr && g.pf_share_inside && n >= 2) {
+      // run length: the makespan of ceil(runs / CUs) runs per workgroup, a resumed window costing ~0.6 of a full one
+      double best = 1e300;
+      for (int t = 1; t <= 16; t++) {
+        const int runs = (n + t - 1) / t, per = (runs + g.n_cu - 1) / g.n_cu;
+        const double cost = per * (1.0 + 0.6 * (t - 1));
+        if (cost < best) { best = cost; run_len = t; }
+      }
+      if (g.pf_run_len > 0) run_len = g.pf_run_len < n ? g.pf_run_len : n;  // SCANFOLD_PF_RUN_LEN (tests)
+      if (run_len > 1) {
+        grid = (n + run_len - 1) / run_len < g.n_cu ? (n + run_len - 1) / run_len : g.n_cu;
+        int rc = ensure(g.pf_share, (size_t)grid * SF_PFL_SHARE_DOUBLES(W) * sizeof(double));
+        if (rc) return rc;
+        share = (double *)g.pf_share.p;
+      }
+    }
     sf_pf_lds_launch(grid, W, st, d_seqs, n, row_stride, W, (const SfDevParams *)g.dP, (const SfDevParamsPF *)g.dX,
-                     d_dG, d_mbd, d_cen, d_cd);
+                     d_dG, d_mbd, d_cen, d_cd, d_tr, L, win0, run_len, share);
   } else if (W >= 16 && W <= SF_PFF_MAXW && !g.force_full) {
     const int pf_blocks = g.n_cu * g.pf_blocks_per_cu;
     grid = n < pf_blocks ? n : pf_blocks;
@@ -304,6 +326,8 @@ int sf_init(int device_ordinal) {
   HIPCHK(sf_dual_configure());
   if (const char *mk = getenv("SCANFOLD_MFE_KERNEL")) g.mfe_kernel = strcmp(mk, "pk") == 0 ? 1 : (strcmp(mk, "dual") == 0 ? 2 : 0);
   if (const char *pk = getenv("SCANFOLD_PF_KERNEL")) g.pf_kernel = (strcmp(pk, "global") == 0);
+  if (const char *ps = getenv("SCANFOLD_PF_SHARE")) g.pf_share_inside = atoi(ps) != 0;
+  if (const char *pr = getenv("SCANFOLD_PF_RUN_LEN")) g.pf_run_len = atoi(pr);
   if (const char *pb = getenv("SCANFOLD_PF_BLOCKS_PER_CU")) g.pf_blocks_per_cu = atoi(pb) > 0 ? atoi(pb) : 4;
   const char *ff = getenv("SCANFOLD_FORCE_FULL");
   g.force_full = (ff && ff[0] == '1');
@@ -315,7 +339,7 @@ int sf_init(int device_ordinal) {
 int sf_shutdown(void) {
   if (!g.init) return SF_OK;
   hipDeviceSynchronize();
-  DevBuf *bufs[] = {&g.full_scratch, &g.pf_scratch, &g.fast_scratch, &g.seqs, &g.energies, &g.db, &g.cen,
+  DevBuf *bufs[] = {&g.full_scratch, &g.pf_scratch, &g.pf_share, &g.fast_scratch, &g.seqs, &g.energies, &g.db, &g.cen,
                     &g.dbl, &g.status, &g.transcript, &g.ovf};
   for (DevBuf *b : bufs) {
     if (b->p) hipFree(b->p);
@@ -488,7 +512,8 @@ int sf_scan_dev(const uint8_t *d_tr, int L, int W, int step, int win_begin, int 
     if ((rc = launch_mfe(d_seqs, nw * (r + 1), W, d_energies + (size_t)w0 * (r + 1), st, r + 1, dbp))) return rc;
     if (!(flags & SF_SCAN_NO_PF)) {
       if ((rc = launch_pf(d_seqs, nw, r + 1, W, d_ens_dG ? d_ens_dG + w0 : nullptr, d_ens_div ? d_ens_div + w0 : nullptr,
-                          d_centroid ? d_centroid + (size_t)w0 * (W + 1) : nullptr, nullptr, st)))
+                          d_centroid ? d_centroid + (size_t)w0 * (W + 1) : nullptr, nullptr, st,
+                          step == 1 ? d_tr : nullptr, L, win_begin + w0)))
         return rc;
     }
   }

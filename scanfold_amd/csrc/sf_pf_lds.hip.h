@@ -61,6 +61,8 @@ __host__ __device__ inline size_t sf_pfl_lds_bytes(int W) {
   const size_t dbl = 2 * NC + 12 * RP + 3 * 625 + 2 * VW + 8 + 6 * VW + 7 * VW + (W + 2) + (W + 3) + 16 + 4 * 32 + (W + 8);
   return dbl * sizeof(double) + 2 * (size_t)(W + 2) * sizeof(int) + (size_t)(W + 8) + 64;
 }
+// doubles per workgroup of the shared-inside state: qb, qm, derived buffers, qm1, 27 registers per centre slot
+#define SF_PFL_SHARE_DOUBLES(W) ((size_t)((W)-4) * ((W)-3) + 12 * ((W) + 2 * SF_PFL_PAD) + 2 * ((W) + 8) + 8 + SF_PFL_SLOTS * 27)
 static inline bool sf_pfl_supported(int W) {
   return W >= 16 && W <= 128 && 2 * W - 4 < 2 * SF_PFL_SLOTS && sf_pfl_lds_bytes(W) <= SF_PFL_LDS_LIMIT;  // (exterior sweeps: two columns per lane)
 }
@@ -90,7 +92,16 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
                                                               double *__restrict__ ens_dG,
                                                               double *__restrict__ mean_bp_dist,
                                                               char *__restrict__ centroid,
-                                                              double *__restrict__ centroid_dist) {
+                                                              double *__restrict__ centroid_dist,
+                                                              const uint8_t *__restrict__ tr, int L, int win0,
+                                                              int run_len, double *__restrict__ share) {
+  // share != null (native windows of one transcript, one nucleotide apart, sf_scan with step 1): a workgroup takes
+  // RUNS of run_len consecutive windows.  The inside tables of window w+1 are those of window w shifted by one row
+  // and one column plus ONE new column — provided the ends of a window are treated like any other position
+  // (neighbours from the transcript): the entries that then differ from a stand-alone fold (first row / last column
+  // of qm, qm1 and the derived buffers) are never read by anything that reaches the outputs.  After the inside pass
+  // the workgroup dumps qb, qm, the derived buffers, qm1 and team 0's recurrence registers to its slice of `share`;
+  // the next window reloads them shifted and runs the column loop for its last column only.
   SF_DYN_SMEM(smem);
   const int W = WT ? WT : Wrt;
   const int tid = threadIdx.x;
@@ -139,11 +150,20 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
   for (int x = tid; x < W + 8; x += SF_PFL_NT) MLB[x] = X->mlbase_pow[x];
   if (tid < 64) PT8[tid] = (uint8_t)D->pair[tid >> 3][tid & 7];
 
-  for (int fold = blockIdx.x; fold < n; fold += gridDim.x) {
+  const bool shared = share != nullptr;
+  const int SV_QM = NC, SV_DER = 2 * NC, SV_QM1 = SV_DER + 12 * RP, SV_H = SV_QM1 + 2 * VW + 8;
+  double *sv = shared ? share + (size_t)blockIdx.x * SF_PFL_SHARE_DOUBLES(W) : nullptr;
+  if (!shared) run_len = 1;
+  for (int fold0 = blockIdx.x * run_len; fold0 < n; fold0 += gridDim.x * run_len)
+  for (int fold = fold0; fold < fold0 + run_len && fold < n; fold++) {
+    const bool resume = shared && fold > fold0;                          // the previous window's state is in sv
+    const bool keep = shared && fold + 1 < fold0 + run_len && fold + 1 < n;  // the next window will want this one's
     const uint8_t *src = seqs + (size_t)fold * row_stride * W;
+    const int pos = win0 + fold;  // window start in the transcript (step 1)
+    const bool nbL = shared && pos > 0, nbR = shared && pos + W < L;
     __syncthreads();
     for (int x = tid; x < W; x += SF_PFL_NT) S[x + 1] = sf_encode_nt(src[x]);
-    if (tid == 0) { S[0] = 0; S[W + 1] = 0; }
+    if (tid == 0) { S[0] = nbL ? sf_encode_nt(tr[pos - 1]) : 0; S[W + 1] = nbR ? sf_encode_nt(tr[pos + W]) : 0; }
     for (int x = tid; x < 12 * RP; x += SF_PFL_NT) DER[x] = 0.0;
     for (int x = tid; x < 15 * VW + 8; x += SF_PFL_NT) QM1[x] = 0.0;  // QM1, the six R vectors, the partial sums
     __syncthreads();
@@ -170,7 +190,30 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
     double H[27];
 #pragma unroll
     for (int u = 0; u < 27; u++) H[u] = 0.0;
-    for (int j = SFD_TURN + 2; j <= W + 1; j++) {
+    if (resume) {
+      const int wv = tid >> 6, ln = tid & 63;
+      // qb: new (i,j) = old (i+1,j+1), columns 5..W-1;  qm: new (d,i) = old (d,i+1)
+      for (int jj = 5 + wv; jj <= W - 1; jj += SF_PFL_NT / 64)
+        for (int ii = 1 + ln; ii <= jj - 4; ii += 64) QBC(ii, jj) = sv[COFF(jj + 1) + ii];
+      for (int dd = 4 + wv; dd <= W - 2; dd += SF_PFL_NT / 64)
+        for (int ii = 1 + ln; ii <= W - 1 - dd; ii += 64) QMD(dd, ii) = sv[SV_QM + DOFF(dd) + ii];
+      // derived buffers of the last three columns, rows shifted; qm1 of the (new) column W-1
+      for (int x = tid; x < 9 * W; x += SF_PFL_NT) {
+        const int kc = x / W, ii = x - kc * W + 1, kind = kc / 3, cn = W - 3 + (kc - kind * 3);
+        DERP(kind, cn)[ii] = sv[SV_DER + (kind * 4 + ((cn + 1) & 3)) * RP + SF_PFL_PAD + ii + 1];
+      }
+      for (int ii = tid + 1; ii <= W; ii += SF_PFL_NT) QM1[((W - 1) & 1) * VW + ii] = sv[SV_QM1 + (W & 1) * VW + ii + 1];
+      if (team == 0) {  // recurrence registers of the cell this thread's cell (i, W) encloses: old cell (i+2, W)
+        const int sW = (W <= c - 1) ? c : c + SF_PFL_SLOTS, iW = sW - W;
+        if (iW >= 1 && iW + 2 <= W) {
+          const double *hp = sv + SV_H + ((iW + 2 + W) & (SF_PFL_SLOTS - 1)) * 27;
+#pragma unroll
+          for (int u = 0; u < 27; u++) H[u] = hp[u];
+        }
+      }
+      __syncthreads();
+    }
+    for (int j = resume ? W : SFD_TURN + 2; j <= W + 1; j++) {
 #ifdef SF_STAMP
       const unsigned long long tc0 = SF_PFT();
 #endif
@@ -294,7 +337,7 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
       } else if (team == 2) {
         if (valid) {
           const int type = OWN(i, j);
-          if (type) wml = sfx_mlstem(X, type, i > 1 ? S[i - 1] : -1, j < W ? S[j + 1] : -1);
+          if (type) wml = sfx_mlstem(X, type, (i > 1 || nbL) ? S[i - 1] : -1, (j < W || nbR) ? S[j + 1] : -1);
         }
         if (valid) {
           const double *d1N2 = DERP(1, j - 2) + i;
@@ -365,6 +408,14 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
 #ifdef SF_STAMP
     const unsigned long long ts1 = SF_PFT();
 #endif
+    if (keep) {  // the inside state for the next window of the run (nothing below reads sv)
+      for (int x = tid; x < 2 * NC + 12 * RP + 2 * VW + 8; x += SF_PFL_NT)
+        sv[x] = x < SV_DER ? QB[x] : (x < SV_QM1 ? DER[x - SV_DER] : QM1[x - SV_QM1]);
+      if (team == 0) {
+#pragma unroll
+        for (int u = 0; u < 27; u++) sv[SV_H + c * 27 + u] = H[u];
+      }
+    }
     // ================= exterior =================
     // q5[j] = q5[j-1] + sum_i q5[i-1] qb[i,j] ExtLoop(i,j) and its mirror image q3, each by ONE wave as a sweep
     // without any reduction across lanes (the block-wide sum + barrier per column this replaces took 15 % of a

@@ -127,6 +127,28 @@ def test_device_shuffles_and_scan(emul, oracle):
         assert oracle.pf(s)["centroid"] == res["centroid"][w]
 
 
+def test_scan_step_one_shares_inside_tables(emul, oracle):
+    """sf_scan with step 1: consecutive native windows reuse the inside tables of their predecessor (shifted by one
+    row and column, one new column computed).  Centroid, ensemble diversity and ensemble energy must equal the
+    stand-alone fold of every window — including windows with an N and the first / last window of the transcript."""
+    rng = np.random.default_rng(11)
+    for W, L in ((40, 75), (31, 64), (120, 131)):
+        tr = "".join("ACGU"[k] for k in rng.integers(0, 4, L))
+        if W == 40:
+            tr = tr[:20] + "N" + tr[21:]
+        nwin = L - W + 1
+        res = emul.scan(tr, W, 1, 0, nwin, 1, 1, 5)
+        for w in range(nwin):
+            o = oracle.pf(tr[w:w + W])
+            assert o["centroid"] == res["centroid"][w], (W, w)
+            assert abs(o["mean_bp_dist"] - res["ens_div"][w]) < 1e-9, (W, w)
+            assert abs(o["dG"] - res["ens_dG"][w]) < 1e-9, (W, w)
+        # a sub-range of windows (different run boundaries) gives the same numbers
+        part = emul.scan(tr, W, 1, 3, nwin - 5, 1, 1, 5)
+        assert part["centroid"] == res["centroid"][3:nwin - 2]
+        assert np.allclose(part["ens_div"], res["ens_div"][3:nwin - 2], rtol=0, atol=1e-9)
+
+
 def test_bad_arguments_return_status(emul):
     from scanfold_amd._lib import ScanFoldHipError
     with pytest.raises(ScanFoldHipError):

@@ -364,3 +364,23 @@ def test_max_bp_span_matches_oracle(gpu_engine, oracle):
         gpu_engine.set_kernel_mode(0)
         gpu_engine.set_max_bp_span(0)
         oracle.set_max_bp_span(0)
+
+
+def test_scan_step_one_shares_inside_tables(gpu_engine, oracle):
+    """sf_scan with step 1 lets consecutive native windows share their partition-function inside tables (runs of up
+    to 16 windows per workgroup once there are more windows than CUs).  Every window must still equal its
+    stand-alone fold: against the oracle, and against the same kernel run on the windows as independent rows."""
+    W = 60
+    tr = synth_transcript(W + 1400 - 1, 77)
+    tr = tr[:500] + "N" + tr[501:]
+    nwin = len(tr) - W + 1
+    res = gpu_engine.scan(tr, W, 1, 0, nwin, 1, 1, 5)
+    wins = [tr[w:w + W] for w in range(nwin)]
+    alone = gpu_engine.pf_batch(wins)
+    assert res["centroid"] == alone["centroid"]
+    assert np.allclose(res["ens_div"], alone["mean_bp_dist"], rtol=1e-12, atol=1e-12)
+    assert np.allclose(res["ens_dG"], alone["dG"], rtol=1e-12, atol=1e-12)
+    for w in range(0, nwin, 7):
+        o = oracle.pf(wins[w])
+        assert o["centroid"] == res["centroid"][w], w
+        assert abs(o["mean_bp_dist"] - res["ens_div"][w]) < PF_TOL and abs(o["dG"] - res["ens_dG"][w]) < PF_TOL, w

@@ -212,7 +212,7 @@ int launch_pf(const uint8_t *d_seqs, int n, int row_stride, int W, double *d_dG,
         share = (double *)g.pf_share.p;
       }
     }
-    sf_pf_lds_launch(grid, W, st, d_seqs, n, row_stride, W, (const SfDevParams *)g.dP, (const SfDevParamsPF *)g.dX,
+    sf_pf_lds_launch(grid, W, share != nullptr, st, d_seqs, n, row_stride, W, (const SfDevParams *)g.dP, (const SfDevParamsPF *)g.dX,
                      d_dG, d_mbd, d_cen, d_cd, d_tr, L, win0, run_len, share);
   } else if (W >= 16 && W <= SF_PFF_MAXW && !g.force_full) {
     const int pf_blocks = g.n_cu * g.pf_blocks_per_cu;

@@ -85,7 +85,7 @@ __device__ unsigned long long sf_pf_stamp_acc[32];  // [0..2] phases, [3] folds,
 #define SF_PFT() __builtin_amdgcn_s_memtime()
 #endif
 
-template <int WT>
+template <int WT, bool SH>
 __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__restrict__ seqs, int n, int row_stride,
                                                               int Wrt, const SfDevParams *__restrict__ D,
                                                               const SfDevParamsPF *__restrict__ X,
@@ -150,17 +150,17 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
   for (int x = tid; x < W + 8; x += SF_PFL_NT) MLB[x] = X->mlbase_pow[x];
   if (tid < 64) PT8[tid] = (uint8_t)D->pair[tid >> 3][tid & 7];
 
-  const bool shared = share != nullptr;
+  const bool shared = SH;  // (a template parameter: the stand-alone instantiation carries none of the extra state)
   const int SV_QM = NC, SV_DER = 2 * NC, SV_QM1 = SV_DER + 12 * RP, SV_H = SV_QM1 + 2 * VW + 8;
-  double *sv = shared ? share + (size_t)blockIdx.x * SF_PFL_SHARE_DOUBLES(W) : nullptr;
+  double *sv = SH ? share + (size_t)blockIdx.x * SF_PFL_SHARE_DOUBLES(W) : nullptr;
   if (!shared) run_len = 1;
   for (int fold0 = blockIdx.x * run_len; fold0 < n; fold0 += gridDim.x * run_len)
   for (int fold = fold0; fold < fold0 + run_len && fold < n; fold++) {
-    const bool resume = shared && fold > fold0;                          // the previous window's state is in sv
-    const bool keep = shared && fold + 1 < fold0 + run_len && fold + 1 < n;  // the next window will want this one's
+    const bool resume = SH && fold > fold0;                          // the previous window's state is in sv
+    const bool keep = SH && fold + 1 < fold0 + run_len && fold + 1 < n;  // the next window will want this one's
     const uint8_t *src = seqs + (size_t)fold * row_stride * W;
     const int pos = win0 + fold;  // window start in the transcript (step 1)
-    const bool nbL = shared && pos > 0, nbR = shared && pos + W < L;
+    const bool nbL = SH && pos > 0, nbR = SH && pos + W < L;
     __syncthreads();
     for (int x = tid; x < W; x += SF_PFL_NT) S[x + 1] = sf_encode_nt(src[x]);
     if (tid == 0) { S[0] = nbL ? sf_encode_nt(tr[pos - 1]) : 0; S[W + 1] = nbR ? sf_encode_nt(tr[pos + W]) : 0; }
@@ -740,16 +740,20 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
 }
 
 static inline hipError_t sf_pfl_configure() {
-  hipError_t e = hipFuncSetAttribute((const void *)sf_pf_lds_kernel<120>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     SF_PFL_LDS_LIMIT);
+  hipError_t e = hipFuncSetAttribute((const void *)sf_pf_lds_kernel<120, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SF_PFL_LDS_LIMIT);
   if (e != hipSuccess) return e;
-  return hipFuncSetAttribute((const void *)sf_pf_lds_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                             SF_PFL_LDS_LIMIT);
+  e = hipFuncSetAttribute((const void *)sf_pf_lds_kernel<120, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SF_PFL_LDS_LIMIT);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void *)sf_pf_lds_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SF_PFL_LDS_LIMIT);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute((const void *)sf_pf_lds_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SF_PFL_LDS_LIMIT);
 }
 
 template <typename... A>
-static inline void sf_pf_lds_launch(int grid, int W, hipStream_t st, A... args) {
+static inline void sf_pf_lds_launch(int grid, int W, bool shared, hipStream_t st, A... args) {
   const size_t lds = sf_pfl_lds_bytes(W);
-  if (W == 120) SF_LAUNCH((sf_pf_lds_kernel<120>), grid, SF_PFL_NT, lds, st, args...);
-  else SF_LAUNCH((sf_pf_lds_kernel<0>), grid, SF_PFL_NT, lds, st, args...);
+  if (W == 120 && shared) SF_LAUNCH((sf_pf_lds_kernel<120, true>), grid, SF_PFL_NT, lds, st, args...);
+  else if (W == 120) SF_LAUNCH((sf_pf_lds_kernel<120, false>), grid, SF_PFL_NT, lds, st, args...);
+  else if (shared) SF_LAUNCH((sf_pf_lds_kernel<0, true>), grid, SF_PFL_NT, lds, st, args...);
+  else SF_LAUNCH((sf_pf_lds_kernel<0, false>), grid, SF_PFL_NT, lds, st, args...);
 }

@@ -188,7 +188,7 @@ int launch_full(const uint8_t *d_seqs, const int *d_idx, const int *d_count, int
 // d_tr != null: the n rows are the native windows of transcript d_tr (length L) that start at win0, win0+1, ...
 // (sf_scan with step 1): consecutive windows share their inside tables (sf_pf_lds.hip.h).
 int launch_pf(const uint8_t *d_seqs, int n, int row_stride, int W, double *d_dG, double *d_mbd, char *d_cen,
-              double *d_cd, hipStream_t st, const uint8_t *d_tr = nullptr, int L = 0, int win0 = 0) {
+              double *d_cd, hipStream_t st, const uint8_t *d_tr = nullptr, int L = 0, int win0 = 0, int step = 1) {
   if (n <= 0) return SF_OK;
   int grid = n < max_resident_blocks() ? n : max_resident_blocks();
   if (sf_pfl_supported(W) && !g.force_full && g.pf_kernel == 0) {
@@ -196,12 +196,14 @@ int launch_pf(const uint8_t *d_seqs, int n, int row_stride, int W, double *d_dG,
     grid = n < g.n_cu ? n : g.n_cu;
     int run_len = 1;
     double *share = nullptr;
-    if (d_tr && g.pf_share_inside && n >= 2) {
-      // run length: the makespan of ceil(runs / CUs) runs per workgroup, a resumed window costing ~0.6 of a full one
+    if (d_tr && g.pf_share_inside && n >= 2 && step >= 1 && step <= W / 4) {
+      // run length: the makespan of ceil(runs / CUs) runs per workgroup; a resumed window costs the outside pass
+      // (~0.6 of a full fold) plus its share of the inside pass
+      const double resumed = 0.6 + 0.4 * step / (double)(W - 4);
       double best = 1e300;
-      for (int t = 1; t <= 16; t++) {
+      for (int t = 1; t <= 64; t++) {
         const int runs = (n + t - 1) / t, per = (runs + g.n_cu - 1) / g.n_cu;
-        const double cost = per * (1.0 + 0.6 * (t - 1));
+        const double cost = per * (1.0 + resumed * (t - 1));
         if (cost < best) { best = cost; run_len = t; }
       }
       if (g.pf_run_len > 0) run_len = g.pf_run_len < n ? g.pf_run_len : n;  // SCANFOLD_PF_RUN_LEN (tests)
@@ -213,7 +215,7 @@ int launch_pf(const uint8_t *d_seqs, int n, int row_stride, int W, double *d_dG,
       }
     }
     sf_pf_lds_launch(grid, W, share != nullptr, st, d_seqs, n, row_stride, W, (const SfDevParams *)g.dP, (const SfDevParamsPF *)g.dX,
-                     d_dG, d_mbd, d_cen, d_cd, d_tr, L, win0, run_len, share);
+                     d_dG, d_mbd, d_cen, d_cd, d_tr, L, win0, step, run_len, share);
   } else if (W >= 16 && W <= SF_PFF_MAXW && !g.force_full) {
     const int pf_blocks = g.n_cu * g.pf_blocks_per_cu;
     grid = n < pf_blocks ? n : pf_blocks;
@@ -513,7 +515,7 @@ int sf_scan_dev(const uint8_t *d_tr, int L, int W, int step, int win_begin, int 
     if (!(flags & SF_SCAN_NO_PF)) {
       if ((rc = launch_pf(d_seqs, nw, r + 1, W, d_ens_dG ? d_ens_dG + w0 : nullptr, d_ens_div ? d_ens_div + w0 : nullptr,
                           d_centroid ? d_centroid + (size_t)w0 * (W + 1) : nullptr, nullptr, st,
-                          step == 1 ? d_tr : nullptr, L, win_begin + w0)))
+                          d_tr, L, win_begin + w0, step)))
         return rc;
     }
   }

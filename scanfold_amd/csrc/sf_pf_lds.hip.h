@@ -94,14 +94,14 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
                                                               char *__restrict__ centroid,
                                                               double *__restrict__ centroid_dist,
                                                               const uint8_t *__restrict__ tr, int L, int win0,
-                                                              int run_len, double *__restrict__ share) {
-  // share != null (native windows of one transcript, one nucleotide apart, sf_scan with step 1): a workgroup takes
-  // RUNS of run_len consecutive windows.  The inside tables of window w+1 are those of window w shifted by one row
-  // and one column plus ONE new column — provided the ends of a window are treated like any other position
+                                                              int step, int run_len, double *__restrict__ share) {
+  // SH (native windows of one transcript, `step` nucleotides apart, sf_scan): a workgroup takes RUNS of run_len
+  // consecutive windows.  The inside tables of window w+1 are those of window w shifted by `step` rows and columns
+  // plus `step` new columns — provided the ends of a window are treated like any other position
   // (neighbours from the transcript): the entries that then differ from a stand-alone fold (first row / last column
   // of qm, qm1 and the derived buffers) are never read by anything that reaches the outputs.  After the inside pass
   // the workgroup dumps qb, qm, the derived buffers, qm1 and team 0's recurrence registers to its slice of `share`;
-  // the next window reloads them shifted and runs the column loop for its last column only.
+  // the next window reloads them shifted and runs the column loop for its last `step` columns only.
   SF_DYN_SMEM(smem);
   const int W = WT ? WT : Wrt;
   const int tid = threadIdx.x;
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
     const bool resume = SH && fold > fold0;                          // the previous window's state is in sv
     const bool keep = SH && fold + 1 < fold0 + run_len && fold + 1 < n;  // the next window will want this one's
     const uint8_t *src = seqs + (size_t)fold * row_stride * W;
-    const int pos = win0 + fold;  // window start in the transcript (step 1)
+    const int pos = (win0 + fold) * step;  // window start in the transcript
     const bool nbL = SH && pos > 0, nbR = SH && pos + W < L;
     __syncthreads();
     for (int x = tid; x < W; x += SF_PFL_NT) S[x + 1] = sf_encode_nt(src[x]);
@@ -192,28 +192,29 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
     for (int u = 0; u < 27; u++) H[u] = 0.0;
     if (resume) {
       const int wv = tid >> 6, ln = tid & 63;
-      // qb: new (i,j) = old (i+1,j+1), columns 5..W-1;  qm: new (d,i) = old (d,i+1)
-      for (int jj = 5 + wv; jj <= W - 1; jj += SF_PFL_NT / 64)
-        for (int ii = 1 + ln; ii <= jj - 4; ii += 64) QBC(ii, jj) = sv[COFF(jj + 1) + ii];
-      for (int dd = 4 + wv; dd <= W - 2; dd += SF_PFL_NT / 64)
-        for (int ii = 1 + ln; ii <= W - 1 - dd; ii += 64) QMD(dd, ii) = sv[SV_QM + DOFF(dd) + ii];
-      // derived buffers of the last three columns, rows shifted; qm1 of the (new) column W-1
+      // k = step.  qb: new (i,j) = old (i+k,j+k), columns 5..W-k;  qm: new (d,i) = old (d,i+k)
+      const int k = step, j0 = W - k + 1;  // j0: first column to compute
+      for (int jj = 5 + wv; jj <= W - k; jj += SF_PFL_NT / 64)
+        for (int ii = 1 + ln; ii <= jj - 4; ii += 64) QBC(ii, jj) = sv[COFF(jj + k) + ii + k - 1];
+      for (int dd = 4 + wv; dd <= W - k - 1; dd += SF_PFL_NT / 64)
+        for (int ii = 1 + ln; ii <= W - k - dd; ii += 64) QMD(dd, ii) = sv[SV_QM + DOFF(dd) + ii + k - 1];
+      // derived buffers of the last three old columns (= new columns j0-3 .. j0-1), rows shifted; qm1 of new column j0-1
       for (int x = tid; x < 9 * W; x += SF_PFL_NT) {
-        const int kc = x / W, ii = x - kc * W + 1, kind = kc / 3, cn = W - 3 + (kc - kind * 3);
-        DERP(kind, cn)[ii] = sv[SV_DER + (kind * 4 + ((cn + 1) & 3)) * RP + SF_PFL_PAD + ii + 1];
+        const int kc = x / W, ii = x - kc * W + 1, kind = kc / 3, cn = j0 - 3 + (kc - kind * 3);
+        if (ii + k <= W) DERP(kind, cn)[ii] = sv[SV_DER + (kind * 4 + ((cn + k) & 3)) * RP + SF_PFL_PAD + ii + k];
       }
-      for (int ii = tid + 1; ii <= W; ii += SF_PFL_NT) QM1[((W - 1) & 1) * VW + ii] = sv[SV_QM1 + (W & 1) * VW + ii + 1];
-      if (team == 0) {  // recurrence registers of the cell this thread's cell (i, W) encloses: old cell (i+2, W)
-        const int sW = (W <= c - 1) ? c : c + SF_PFL_SLOTS, iW = sW - W;
-        if (iW >= 1 && iW + 2 <= W) {
-          const double *hp = sv + SV_H + ((iW + 2 + W) & (SF_PFL_SLOTS - 1)) * 27;
+      for (int ii = tid + 1; ii + k <= W + 1; ii += SF_PFL_NT) QM1[((j0 - 1) & 1) * VW + ii] = sv[SV_QM1 + (W & 1) * VW + ii + k];
+      if (team == 0) {  // recurrence registers of the cell this thread's cell (i, j0) encloses: old cell (i+1+k, W)
+        const int sW = (j0 <= c - 1) ? c : c + SF_PFL_SLOTS, iW = sW - j0;
+        if (iW >= 1 && iW + 1 + k <= W) {
+          const double *hp = sv + SV_H + ((iW + 1 + k + W) & (SF_PFL_SLOTS - 1)) * 27;
 #pragma unroll
           for (int u = 0; u < 27; u++) H[u] = hp[u];
         }
       }
       __syncthreads();
     }
-    for (int j = resume ? W : SFD_TURN + 2; j <= W + 1; j++) {
+    for (int j = resume ? W - step + 1 : SFD_TURN + 2; j <= W + 1; j++) {
 #ifdef SF_STAMP
       const unsigned long long tc0 = SF_PFT();
 #endif

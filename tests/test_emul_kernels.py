@@ -147,6 +147,15 @@ def test_scan_step_one_shares_inside_tables(emul, oracle):
         part = emul.scan(tr, W, 1, 3, nwin - 5, 1, 1, 5)
         assert part["centroid"] == res["centroid"][3:nwin - 2]
         assert np.allclose(part["ens_div"], res["ens_div"][3:nwin - 2], rtol=0, atol=1e-9)
+    # windows more than one nucleotide apart: `step` new columns per window
+    tr = "".join("ACGU"[k] for k in rng.integers(0, 4, 150))
+    for W, step in ((48, 2), (48, 7), (40, 10)):
+        nwin = (len(tr) - W) // step + 1
+        res = emul.scan(tr, W, step, 0, nwin, 1, 1, 5)
+        for w in range(nwin):
+            o = oracle.pf(tr[w * step:w * step + W])
+            assert o["centroid"] == res["centroid"][w], (W, step, w)
+            assert abs(o["mean_bp_dist"] - res["ens_div"][w]) < 1e-9 and abs(o["dG"] - res["ens_dG"][w]) < 1e-9, (W, step, w)
 
 
 def test_bad_arguments_return_status(emul):

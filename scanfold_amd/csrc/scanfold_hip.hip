@@ -201,7 +201,7 @@ int launch_pf(const uint8_t *d_seqs, int n, int row_stride, int W, double *d_dG,
       // (~0.6 of a full fold) plus its share of the inside pass
       const double resumed = 0.6 + 0.4 * step / (double)(W - 4);
       double best = 1e300;
-      for (int t = 1; t <= 64; t++) {
+      for (int t = 1; t <= 128; t++) {
         const int runs = (n + t - 1) / t, per = (runs + g.n_cu - 1) / g.n_cu;
         const double cost = per * (1.0 + resumed * (t - 1));
         if (cost < best) { best = cost; run_len = t; }

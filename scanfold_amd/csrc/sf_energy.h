@@ -20,22 +20,29 @@ __device__ __forceinline__ uint32_t sfd_loop_key(const uint8_t *S, int i, int le
   return k;
 }
 
+// Index of the special hairpin whose key matches the loop closed at i (first match), or -1.  No early exit: the key
+// table reads are wave-uniform and independent, so they are fetched in batches instead of one round trip per entry
+// (the short-diagonal steps of the MFE kernels spent most of their time in that chain).
 __device__ inline int sfd_special_hairpin(const SfDevParams *D, const uint8_t *S, int i, int size, int *found) {
-  *found = 0;
+  int idx = -1;
   if (size == 4) {
-    uint32_t key = sfd_loop_key(S, i, 6);
-    for (int k = 0; k < D->P.n_tetra; k++)
-      if (D->tetra_key[k] == key) { *found = 1; return k; }
+    const uint32_t key = sfd_loop_key(S, i, 6);
+    const int n = D->P.n_tetra;
+#pragma unroll 8
+    for (int k = 0; k < n; k++) idx = (idx < 0 && D->tetra_key[k] == key) ? k : idx;
   } else if (size == 6) {
-    uint32_t key = sfd_loop_key(S, i, 8);
-    for (int k = 0; k < D->P.n_hexa; k++)
-      if (D->hexa_key[k] == key) { *found = 1; return k; }
+    const uint32_t key = sfd_loop_key(S, i, 8);
+    const int n = D->P.n_hexa;
+#pragma unroll 4
+    for (int k = 0; k < n; k++) idx = (idx < 0 && D->hexa_key[k] == key) ? k : idx;
   } else if (size == 3) {
-    uint32_t key = sfd_loop_key(S, i, 5);
-    for (int k = 0; k < D->P.n_tri; k++)
-      if (D->tri_key[k] == key) { *found = 1; return k; }
+    const uint32_t key = sfd_loop_key(S, i, 5);
+    const int n = D->P.n_tri;
+#pragma unroll 4
+    for (int k = 0; k < n; k++) idx = (idx < 0 && D->tri_key[k] == key) ? k : idx;
   }
-  return -1;
+  *found = idx >= 0;
+  return idx;
 }
 
 __device__ inline int sfd_hairpin(const SfDevParams *D, const uint8_t *S, int i, int j, int type) {

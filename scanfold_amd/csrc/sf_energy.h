@@ -20,29 +20,22 @@ __device__ __forceinline__ uint32_t sfd_loop_key(const uint8_t *S, int i, int le
   return k;
 }
 
-// Index of the special hairpin whose key matches the loop closed at i (first match), or -1.  No early exit: the key
-// table reads are wave-uniform and independent, so they are fetched in batches instead of one round trip per entry
-// (the short-diagonal steps of the MFE kernels spent most of their time in that chain).
 __device__ inline int sfd_special_hairpin(const SfDevParams *D, const uint8_t *S, int i, int size, int *found) {
-  int idx = -1;
+  *found = 0;
   if (size == 4) {
-    const uint32_t key = sfd_loop_key(S, i, 6);
-    const int n = D->P.n_tetra;
-#pragma unroll 8
-    for (int k = 0; k < n; k++) idx = (idx < 0 && D->tetra_key[k] == key) ? k : idx;
+    uint32_t key = sfd_loop_key(S, i, 6);
+    for (int k = 0; k < D->P.n_tetra; k++)
+      if (D->tetra_key[k] == key) { *found = 1; return k; }
   } else if (size == 6) {
-    const uint32_t key = sfd_loop_key(S, i, 8);
-    const int n = D->P.n_hexa;
-#pragma unroll 4
-    for (int k = 0; k < n; k++) idx = (idx < 0 && D->hexa_key[k] == key) ? k : idx;
+    uint32_t key = sfd_loop_key(S, i, 8);
+    for (int k = 0; k < D->P.n_hexa; k++)
+      if (D->hexa_key[k] == key) { *found = 1; return k; }
   } else if (size == 3) {
-    const uint32_t key = sfd_loop_key(S, i, 5);
-    const int n = D->P.n_tri;
-#pragma unroll 4
-    for (int k = 0; k < n; k++) idx = (idx < 0 && D->tri_key[k] == key) ? k : idx;
+    uint32_t key = sfd_loop_key(S, i, 5);
+    for (int k = 0; k < D->P.n_tri; k++)
+      if (D->tri_key[k] == key) { *found = 1; return k; }
   }
-  *found = idx >= 0;
-  return idx;
+  return -1;
 }
 
 __device__ inline int sfd_hairpin(const SfDevParams *D, const uint8_t *S, int i, int j, int type) {

@@ -4,22 +4,28 @@
 One "step" = one full pass of the hot path over the workload: for every window of the synthetic transcript,
 the native MFE fold + traceback, the partition function (centroid, ensemble diversity), r dinucleotide shuffles
 generated on the device and r+1 MFE folds (ScanFold-Scan.py:355-449).  Transcript and all outputs are
-resident in HBM when the timed region starts.  With N>1 ranks (one process per GPU, launched by
-torch.distributed.run) the windows are split into contiguous ranges and each step ends with ONE RCCL
-all-gather of the fixed-size per-window records (scanfold_amd/dist.py); total work is fixed -> "strong".
+resident in HBM when the timed region starts.  With N>1 ranks (one process per GPU) the windows are split into
+contiguous ranges and each step ends with ONE RCCL all-gather of the fixed-size per-window records
+(scanfold_amd/dist.py); total work is fixed -> "strong".
+
+`python bench.py --gpus N` works both ways: under `python -m torch.distributed.run --nproc-per-node N` (RANK /
+WORLD_SIZE in the environment) it is one rank; started plainly with N > 1 it starts that launcher as a CHILD
+process (never exec), relays the child's JSON line and exits with its code.
 
 Workload at N=1: BASELINE.json configs[2] ("30 kb, W=120, step=1, 100 shuffles on 1 MI355X") — the configuration
 the metric is quoted on; it fits one GPU.
+
+After the timed region rank 0 checks 64 windows of the last step against the oracle ("verified_windows"), and at
+N=1 adds an "e2e" block (the CLI's whole path: H2D, kernels, D2H, z/p-scores, TSV rows) and the CPU baseline.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -28,29 +34,82 @@ if ROOT not in sys.path:
 WORKLOAD = dict(name="cfg3: 30 kb synthetic RNA, W=120, step=1, 100 di-shuffles", L=30000, seed=3, W=120, step=1,
                 r=100, shuffle="di", shuffle_seed=2026)
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+VERIFY_WINDOWS = 64
+EXIT_NEED_GPUS = 3
 
 
 def synth_transcript(L, seed):
+    import numpy as np
     return "".join("ACGU"[k] for k in np.random.default_rng(seed).integers(0, 4, L))
 
 
-def cpu_baseline(eng, seq, W, step, r, kind, seed, budget_s=15.0):
-    """The oracle (a CPU port of the ViennaRNA-shaped path; see oracle/sf_oracle.c) on a bounded sample of the
-    same workload: per window 1 MFE + traceback, 1 partition function and r+1 MFE folds, one OpenMP thread per
-    window on every host core.  Baseline only — never the product."""
+def relaunch_under_torchrun(args):
+    """--gpus N without a launcher around us: be the launcher's parent.  Nothing in this process has touched the
+    GPU (torch is not even imported yet)."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__),
+           "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup)]
+    if args.no_cpu_baseline:
+        cmd.append("--no-cpu-baseline")
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line)
+    elif proc.returncode == 0:
+        print("bench.py: the %d-rank run produced no result line" % args.gpus, file=sys.stderr)
+        return 1
+    return proc.returncode
+
+
+def host_cores():
+    """(threads this process may run on, physical cores among them, sockets) — physical = distinct (package, core)."""
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        cpus = list(range(os.cpu_count() or 1))
+    phys, socks = set(), set()
+    for c in cpus:
+        try:
+            base = "/sys/devices/system/cpu/cpu%d/topology/" % c
+            pkg = open(base + "physical_package_id").read().strip()
+            core = open(base + "core_id").read().strip()
+            phys.add((pkg, core))
+            socks.add(pkg)
+        except OSError:
+            phys.add(("?", str(c)))
+    return len(cpus), len(phys), max(len(socks), 1)
+
+
+def cpu_baseline(seq, W, step, r, kind, seed, budget_s=15.0):
+    """The CPU engine (oracle/sf_cpu_twin.c when built, else the checker oracle/sf_oracle.c) on a bounded sample of
+    the same workload: per window 1 MFE + traceback, 1 partition function and r+1 MFE folds, one OpenMP thread per
+    window, threads = physical cores.  Baseline only — never the product, never ViennaRNA (absent)."""
+    import numpy as np
     from oracle import oracle
     from scanfold_amd import params
     oracle.build()
     oracle.set_params(params.default_params())
-    try:
-        cores = len(os.sched_getaffinity(0)) or 1  # the threads this process may actually run on
-    except AttributeError:
-        cores = os.cpu_count() or 1
+    threads, phys, socks = host_cores()
+    cores = phys
+    engine = "oracle/sf_oracle.c (the parity checker: O(n^4) outside pass, dense interior-loop search)"
+    scan_fn = oracle.scan_windows
+    if hasattr(oracle, "twin_available") and oracle.twin_available():
+        engine = "oracle/sf_cpu_twin.c (O(n^3) passes, incremental interior loops)"
+        scan_fn = oracle.twin_scan_windows
 
     def run(n_win):
-        rows = np.frombuffer(b"NACGU", dtype=np.uint8)[eng.shuffle_windows(seq, W, step, 0, n_win, r, kind, seed)]
+        rows = np.frombuffer(b"NACGU", dtype=np.uint8)[oracle.shuffle_windows(seq, W, step, 0, n_win, r, kind, seed)]
         t0 = time.perf_counter()
-        oracle.scan_windows(rows, n_win, r, nthreads=cores)
+        scan_fn(rows, n_win, r, nthreads=cores)
         return time.perf_counter() - t0
     n0 = max(cores, 8)
     t0 = run(n0)
@@ -58,9 +117,37 @@ def cpu_baseline(eng, seq, W, step, r, kind, seed, budget_s=15.0):
     n = (n // cores) * cores or n0
     t = run(n)
     return dict(value=n / t, unit="windows/s", cores=cores, kind="port",
-                sample="first %d windows of the workload, one OpenMP thread per window on %d threads (each window: "
-                       "1 MFE + traceback, 1 partition function, %d MFE folds), %.1f s wall; oracle/sf_oracle.c, "
-                       "not ViennaRNA (absent)" % (n, cores, r + 1, t))
+                sample="first %d windows of the workload, one OpenMP thread per window on %d threads = the physical "
+                       "cores of %d socket(s) (%d hardware threads visible); each window: 1 MFE + traceback, 1 "
+                       "partition function, %d MFE folds; %.1f s wall; engine: %s — not ViennaRNA (absent)"
+                       % (n, cores, socks, threads, r + 1, t, engine))
+
+
+def verify_sample(seq, W, step, r, kind, seed, lo, n_loc, en, db, cen, div, n_check=VERIFY_WINDOWS):
+    """Compare n_check windows of the LAST timed step (device tensors of rank 0's shard) with the oracle: every one
+    of the r+1 energies on the oracle's own shuffles, structure, centroid, ensemble diversity.  Returns
+    (windows checked, mismatching windows)."""
+    import numpy as np
+    from oracle import oracle
+    from scanfold_amd import params
+    oracle.build()
+    oracle.set_params(params.default_params())
+    n_check = min(n_check, n_loc)
+    if n_check <= 0:
+        return 0, 0
+    idx = np.unique(np.linspace(0, n_loc - 1, n_check).astype(np.int64))
+    e_dev = en[idx].cpu().numpy()
+    db_dev = db[idx].cpu().numpy()
+    cen_dev = cen[idx].cpu().numpy()
+    div_dev = div[idx].cpu().numpy()
+    rows = np.concatenate([oracle.shuffle_windows(seq, W, step, lo + int(w), 1, r, kind, seed) for w in idx])
+    ref = oracle.scan_windows(np.frombuffer(b"NACGU", dtype=np.uint8)[rows], len(idx), r)
+    bad = 0
+    for k in range(len(idx)):
+        ok = (ref["energies"][k] == e_dev[k]).all() and ref["structure"][k] == bytes(db_dev[k, :W]).decode() \
+            and ref["centroid"][k] == bytes(cen_dev[k, :W]).decode() and abs(ref["ens_div"][k] - div_dev[k]) < 1e-8
+        bad += 0 if ok else 1
+    return len(idx), bad
 
 
 def main():
@@ -70,22 +157,31 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return relaunch_under_torchrun(args)
 
+    import numpy as np  # noqa: F401
     import torch
     import torch.distributed as dist
-    from scanfold_amd import _lib, dist as sdist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+        return 2
+    n_dev = torch.cuda.device_count()  # does not initialise the GPU
+    if n_dev < world or local_rank >= n_dev:
+        print("bench.py rank %d: --gpus %d needs %d GPUs, %d GPU(s) visible" % (rank, args.gpus, world, n_dev),
+              file=sys.stderr)
+        return EXIT_NEED_GPUS
+    from scanfold_amd import _lib, dist as sdist
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # SCANFOLD_BENCH_FORCE_DIST=1 (under torch.distributed.run --nproc-per-node 1): take the RCCL path with a single
-    # rank, to check process-group set-up, record packing and the all-gather on a one-GPU box
-    use_dist = world > 1 or os.environ.get("SCANFOLD_BENCH_FORCE_DIST") == "1"
+    # rank — process group, record packing and a one-rank all_gather_into_tensor — on a one-GPU box
+    force_dist = os.environ.get("SCANFOLD_BENCH_FORCE_DIST") == "1"
+    use_dist = world > 1 or force_dist
     if use_dist:
         dist.init_process_group("nccl", device_id=dev)
     eng = _lib.Engine(device=local_rank)
@@ -112,7 +208,7 @@ def main():
                      db.data_ptr(), cen.data_ptr(), div.data_ptr(), dG.data_ptr(), st)
         if use_dist:
             rec = sdist.pack_records(torch, W, r, en[:n_loc], db[:n_loc], cen[:n_loc], div[:n_loc], dG[:n_loc], n_pad)
-            return sdist.gather_records(rec, world)
+            return sdist.gather_records(rec, world, force=force_dist)
         return None
 
     def sync():
@@ -134,20 +230,28 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kern_ms, launches, folds = eng.prof_get()
+    dev_status = eng.last_status() if hasattr(eng, "last_status") else 0
 
+    rc = 0
     if rank == 0:
         value = n_win * args.steps / elapsed
         bytes_per_fold = W + 4  # W one-byte nucleotides in, one int32 energy out
         avg_ms = kern_ms / max(launches, 1)
         folds_per_launch = folds / max(launches, 1)
         achieved = folds_per_launch * bytes_per_fold / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic, secondary, counters_src = None, None, None
+        for cand in ("profiles/r02/mfe_counters.json", "profiles/pmc_traffic.json"):
+            path = os.path.join(ROOT, cand)
+            if os.path.exists(path):
+                try:
+                    j = json.load(open(path))
+                    traffic = j.get("hbm_bytes_per_launch")
+                    secondary = j.get("secondary")
+                    counters_src = cand
+                    break
+                except Exception:
+                    pass
+        checked, bad = verify_sample(seq, W, step, r, kind, wl["shuffle_seed"], lo, n_loc, en, db, cen, div)
         out = {
             "metric": "windows/sec (W=120, step=1, 100 shuffles)",
             "value": value, "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -159,21 +263,46 @@ def main():
                        "parallelism": "windows sharded over %d rank(s), one all-gather per step" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "traffic_source": counters_src and (counters_src + " (rocprofv3 --pmc passes of this command, "
+                                                             "separate runs; not collected inside this run)"),
                          "kernel": "sf_mfe_fast_kernel", "avg_launch_ms": avg_ms, "launches": launches,
                          "folds_per_launch": folds_per_launch, "algorithmic_bytes_per_fold": bytes_per_fold,
                          "note": "integer min-plus DP on LDS-resident tables: LDS/VALU-bound by construction "
-                                 "(SURVEY.md F9); HBM fraction reported as the north star asks",
+                                 "(SURVEY.md F9); HBM fraction reported as the north star asks; the unit that bounds "
+                                 "the kernel is in `secondary`",
+                         "secondary": secondary,
                          "mfe_kernel_share_of_step": (kern_ms * 1e-3) / elapsed},
+            "verified_windows": checked, "verified_mismatches": bad, "device_status": dev_status,
+            "verified_against": "oracle (sf_oracle.c + sf_shuffle_oracle.c): all %d energies, structure, centroid, "
+                                "ensemble diversity of %d windows of the last timed step" % (r + 1, checked),
+            "params": eng.params.source and os.path.basename(eng.params.source),
             "device": eng.device_name(),
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(eng, seq, W, step, r, kind, wl["shuffle_seed"])
-            out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        if bad or dev_status:
+            rc = 4
+        if world == 1:
+            from scanfold_amd import scan as scanmod
+            times, nbytes = [], 0
+            scanmod.scan_record(seq, W, step, r, wl["shuffle"], 37, eng, seed=wl["shuffle_seed"])  # warm-up
+            for _ in range(5):
+                t0 = time.perf_counter()
+                rows = scanmod.scan_record(seq, W, step, r, wl["shuffle"], 37, eng, seed=wl["shuffle_seed"])
+                times.append(time.perf_counter() - t0)
+                nbytes = sum(len(x) for x in rows)
+            med = sorted(times)[len(times) // 2]
+            out["e2e"] = {"windows_per_s": n_win / med, "median_s": med, "runs": len(times), "min_s": min(times),
+                          "max_s": max(times), "tsv_bytes": nbytes, "ratio_to_device_resident": (n_win / med) / value,
+                          "what": "scan.scan_record(): transcript H2D, all kernels, D2H, z/p-scores, TSV rows; host "
+                                  "formatting of chunk k overlaps the GPU on chunk k+1 (%d-window chunks)"
+                                  % scanmod.CHUNK_WINDOWS}
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(seq, W, step, r, kind, wl["shuffle_seed"])
         print(json.dumps(out))
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    return rc
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -99,6 +99,11 @@ int sf_scan_dev(const uint8_t *d_transcript, int L, int W, int step, int win_beg
                 int shuffle_kind, uint64_t seed, unsigned flags, int32_t *d_energies, char *d_structure,
                 char *d_centroid, double *d_ens_div, double *d_ens_dG, void *stream);
 
+/* Outcome of the asynchronous "_dev" calls: waits for all work queued on the device, then returns SF_ERR_INTERNAL if
+ * any traceback since the last report found no decomposition of a cell (never seen; it would be a kernel bug), else
+ * SF_OK, and clears the flag.  The host-pointer calls (sf_scan, sf_mfe_trace_batch) report it themselves. */
+int sf_last_status(void);
+
 /* Maximum base-pair span of the folding model.  Replaces md.max_bp_span = args.span (ScanFold.py:214-215; the
  * Scan stage script has no such flag): base pairs (i, j) with j - i + 1 > span do not exist, in the MFE fill, the
  * partition function and the traceback.  span <= 0 removes the limit (the default).  Survives sf_params_load.
@@ -112,9 +117,12 @@ int sf_set_max_bp_span(int span);
 int sf_set_kernel_mode(int mode);
 
 /* Measurement support for bench.py: HIP-event time (ms) and launch count of the dominant kernel
- * (the batched MFE fill) accumulated since the last reset, measured on the stream it was launched on. */
+ * (the batched MFE fill) accumulated since the last reset, measured on the stream it was launched on.
+ * Events are recorded only between sf_prof_reset (turns profiling on) and sf_prof_stop; outside, no event is
+ * ever created.  At most 1024 pairs are pending at a time (older ones are folded into the sum). */
 int sf_prof_reset(void);
 int sf_prof_get(double *mfe_kernel_ms, int64_t *mfe_kernel_launches, int64_t *mfe_folds);
+int sf_prof_stop(void);
 
 #ifdef __cplusplus
 }

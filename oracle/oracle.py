@@ -14,8 +14,8 @@ _lib = None
 
 
 def build(force=False):
-    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(
-            os.path.join(_HERE, "sf_oracle.c")):
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith(".c")]
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
 
 
@@ -36,6 +36,8 @@ def lib():
                              ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
         L.sfo_scan_windows.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        L.sfo_shuffle_windows.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.c_void_p]
         _lib = L
     return _lib
 
@@ -128,3 +130,15 @@ def scan_windows(rows, n_win, r, nthreads=0):
         raise RuntimeError("sfo_scan_windows rc=%d" % rc)
     return dict(energies=en, structure=[bytes(x[:W]).decode() for x in db],
                 centroid=[bytes(x[:W]).decode() for x in cen], ens_div=ed)
+
+
+def shuffle_windows(transcript, W, step, win_begin, n_win, r, kind, seed):
+    """The shuffle background on the product's Philox stream (sf_shuffle_oracle.c): uint8 codes
+    (n_win*(r+1), W), same contract as Engine.shuffle_windows."""
+    tr = transcript.encode("ascii") if isinstance(transcript, str) else bytes(transcript)
+    out = np.empty((n_win * (r + 1), W), dtype=np.uint8)
+    rc = lib().sfo_shuffle_windows(tr, len(tr), W, step, win_begin, n_win, r, kind, ctypes.c_uint64(seed),
+                                   out.ctypes.data)
+    if rc:
+        raise RuntimeError("sfo_shuffle_windows rc=%d" % rc)
+    return out

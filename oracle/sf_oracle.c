@@ -137,7 +137,19 @@ int sfo_set_params(const void *blob, size_t n) {
   pair_tab[4][3] = 4; /* UG */
   pair_tab[1][4] = 5; /* AU */
   pair_tab[4][1] = 6; /* UA */
-  build_exp_params();
+  build_exp_params(); /* Boltzmann weights come from the values as given (through SMOOTH) ... */
+  /* ... while the MFE model uses dangle / multiloop / exterior mismatch terms clamped to <= 0: ViennaRNA's
+   * get_scaled_params stores them as min(0, x) ("must be <= 0") [EXT].  Turner 2004 has no positive entry, so this
+   * only matters for user-supplied sets (Turner 1999, Andronescu) and the randomised test tables. */
+  for (int t = 0; t < 8; t++)
+    for (int a = 0; a < 5; a++) {
+      P.dangle5[t][a] = MIN2(0, P.dangle5[t][a]);
+      P.dangle3[t][a] = MIN2(0, P.dangle3[t][a]);
+      for (int b = 0; b < 5; b++) {
+        P.mismatchM[t][a][b] = MIN2(0, P.mismatchM[t][a][b]);
+        P.mismatchExt[t][a][b] = MIN2(0, P.mismatchExt[t][a][b]);
+      }
+    }
   have_params = 1;
   return 0;
 }

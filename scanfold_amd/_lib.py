@@ -42,6 +42,8 @@ _EXPORTS = {
                                    ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint, ctypes.c_void_p,
                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                    ctypes.c_void_p]),
+    "sf_last_status": (ctypes.c_int, []),
+    "sf_prof_stop": (ctypes.c_int, []),
     "sf_set_kernel_mode": (ctypes.c_int, [ctypes.c_int]),
     "sf_set_max_bp_span": (ctypes.c_int, [ctypes.c_int]),
     "sf_prof_reset": (ctypes.c_int, []),
@@ -174,8 +176,9 @@ class Engine:
                                                 ctypes.c_uint64(seed), out.ctypes.data))
         return out
 
-    def scan(self, transcript, W, step, win_begin, n_win, r, kind, seed, flags=0):
-        """-> dict(energies int32 (n_win, r+1), structure [str], centroid [str], ens_div, ens_dG)"""
+    def scan(self, transcript, W, step, win_begin, n_win, r, kind, seed, flags=0, raw=False):
+        """-> dict(energies int32 (n_win, r+1), structure [str], centroid [str], ens_div, ens_dG);
+        raw=True leaves structure / centroid as the uint8 arrays (n_win, W+1) the library filled."""
         tr = np.frombuffer(transcript.encode("ascii") if isinstance(transcript, str) else bytes(transcript),
                            dtype=np.uint8)
         en = np.empty((n_win, r + 1), dtype=np.int32)
@@ -186,6 +189,8 @@ class Engine:
         self._check(self.lib.sf_scan(tr.ctypes.data, len(tr), W, step, win_begin, n_win, r, kind,
                                      ctypes.c_uint64(seed), flags, en.ctypes.data, db.ctypes.data, cen.ctypes.data,
                                      div.ctypes.data, dG.ctypes.data))
+        if raw:
+            return dict(energies=en, structure=db, centroid=cen, ens_div=div, ens_dG=dG)
         return dict(energies=en, structure=[bytes(x[:W]).decode() for x in db],
                     centroid=[bytes(x[:W]).decode() for x in cen], ens_div=div, ens_dG=dG)
 
@@ -197,6 +202,16 @@ class Engine:
                  d_centroid, d_ens_div, d_ens_dG, stream=0):
         self._check(self.lib.sf_scan_dev(d_transcript, L, W, step, win_begin, n_win, r, kind, ctypes.c_uint64(seed),
                                          flags, d_energies, d_structure, d_centroid, d_ens_div, d_ens_dG, stream))
+
+    def last_status(self):
+        """0, or SF_ERR_INTERNAL (-8) if a traceback of an asynchronous call failed; waits for the device."""
+        rc = self.lib.sf_last_status()
+        if rc not in (0, -8):
+            self._check(rc)
+        return rc
+
+    def prof_stop(self):
+        self._check(self.lib.sf_prof_stop())
 
     def set_kernel_mode(self, mode):
         self._check(self.lib.sf_set_kernel_mode(int(mode)))
@@ -226,4 +241,5 @@ def get_engine(device=None):
         if device is None:
             device = int(os.environ.get("LOCAL_RANK", "0"))
         _engine = Engine(device=device)
+        _params.warn_if_reconstructed(_engine.params)  # the shipped table is not ViennaRNA's: say so once
     return _engine

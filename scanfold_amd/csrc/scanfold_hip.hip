@@ -44,7 +44,8 @@ struct Ctx {
   DevBuf full_scratch, pf_scratch, pf_share, fast_scratch, seqs, energies, db, cen, dbl, status, transcript, ovf;
   std::string last_hip_error;
   // profiling of the dominant kernel
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;  // recorded only while profiling is on (sf_prof_reset)
+  bool prof_on = false;
   double prof_ms = 0.0;
   int64_t prof_launches = 0, prof_folds = 0;
   int force_full = 0;
@@ -166,6 +167,17 @@ void build_dev_params(const sf_params_blob &P, SfDevParams &D, SfDevParamsPF &X)
   }
   X.mlbase_pow[0] = 1.0;
   for (int k = 1; k <= SF_MAX_W + 1; k++) X.mlbase_pow[k] = X.mlbase_pow[k - 1] * X.MLbase;
+  // MFE model: dangle / multiloop / exterior mismatch terms are stored as min(0, x), as ViennaRNA's get_scaled_params
+  // does ("must be <= 0") [EXT]; the Boltzmann weights above come from the unclamped values through SMOOTH().
+  for (int t = 0; t < 8; t++)
+    for (int a = 0; a < 5; a++) {
+      if (D.P.dangle5[t][a] > 0) D.P.dangle5[t][a] = 0;
+      if (D.P.dangle3[t][a] > 0) D.P.dangle3[t][a] = 0;
+      for (int b = 0; b < 5; b++) {
+        if (D.P.mismatchM[t][a][b] > 0) D.P.mismatchM[t][a][b] = 0;
+        if (D.P.mismatchExt[t][a][b] > 0) D.P.mismatchExt[t][a][b] = 0;
+      }
+    }
 }
 
 int max_resident_blocks() { return g.n_cu * 4; }
@@ -176,8 +188,6 @@ int launch_full(const uint8_t *d_seqs, const int *d_idx, const int *d_count, int
   if (n <= 0) return SF_OK;
   int grid = n < max_resident_blocks() ? n : max_resident_blocks();
   int rc = ensure(g.full_scratch, (size_t)grid * SF_FULL_SCRATCH_INTS(W) * sizeof(int32_t));
-  if (rc) return rc;
-  rc = ensure(g.status, sizeof(int));
   if (rc) return rc;
   SF_LAUNCH(sf_mfe_full_kernel, grid, block_threads(W), 0, st, d_seqs, d_idx, d_count, n, row_stride, mfe_stride, W,
             (const SfDevParams *)g.dP, (int32_t *)g.full_scratch.p, d_mfe, d_db, db_stride, (int *)g.status.p);
@@ -235,19 +245,68 @@ int launch_pf(const uint8_t *d_seqs, int n, int row_stride, int W, double *d_dG,
 
 // energies of n rows: LDS-resident int16 kernel, then the exact int32 kernel on the rows it flagged.
 // If d_db, every row that is a multiple of trace_stride also gets its structure, row/trace_stride-th string.
+// HIP events around the dominant kernel, only while profiling is on; a failed call never leaks a pair
+struct ProfPair {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  bool armed = false;
+  int begin(hipStream_t st) {
+    if (!g.prof_on) return SF_OK;
+    if (g.ev.size() >= 1024) {  // bounded: fold what has accumulated into the running sum
+      int rc = prof_drain();
+      if (rc) return rc;
+    }
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventRecord(e0, st) != hipSuccess) {
+      drop();
+      g.last_hip_error = "hipEventCreate/Record failed in launch_mfe";
+      return SF_ERR_HIP;
+    }
+    armed = true;
+    return SF_OK;
+  }
+  int end(hipStream_t st) {
+    if (!armed) return SF_OK;
+    if (hipEventRecord(e1, st) != hipSuccess) {
+      drop();
+      g.last_hip_error = "hipEventRecord failed in launch_mfe";
+      return SF_ERR_HIP;
+    }
+    g.ev.push_back({e0, e1});
+    armed = false;
+    e0 = e1 = nullptr;
+    return SF_OK;
+  }
+  void drop() {
+    if (e0) hipEventDestroy(e0);
+    if (e1) hipEventDestroy(e1);
+    e0 = e1 = nullptr;
+    armed = false;
+  }
+  ~ProfPair() { drop(); }
+  static int prof_drain() {
+    for (auto &e : g.ev) {
+      float t = 0.f;
+      hipError_t err = hipEventSynchronize(e.second);
+      if (err == hipSuccess) err = hipEventElapsedTime(&t, e.first, e.second);
+      hipEventDestroy(e.first);
+      hipEventDestroy(e.second);
+      if (err == hipSuccess) g.prof_ms += t;
+    }
+    g.ev.clear();
+    return SF_OK;
+  }
+};
+
 int launch_mfe(const uint8_t *d_seqs, int n, int W, int32_t *d_out, hipStream_t st, int trace_stride = 1,
                char *d_db = nullptr) {
   if (n <= 0) return SF_OK;
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  HIPCHK(hipEventCreate(&e0));
-  HIPCHK(hipEventCreate(&e1));
+  ProfPair prof;
   int rc = SF_OK;
   if (g.force_full || !g.fast_ok || !sf_fast_w_supported(W)) {
-    HIPCHK(hipEventRecord(e0, st));
+    if ((rc = prof.begin(st))) return rc;
     rc = launch_full(d_seqs, nullptr, nullptr, n, 1, 1, W, d_out, d_db, d_db ? trace_stride : 0, st);
-    HIPCHK(hipEventRecord(e1, st));
+    if (rc) return rc;
+    if ((rc = prof.end(st))) return rc;
   } else {
-    if ((rc = ensure(g.status, sizeof(int)))) return rc;
     rc = ensure(g.ovf, sizeof(int) * ((size_t)n + 1));
     if (rc) return rc;
     int *d_cnt = (int *)g.ovf.p, *d_list = d_cnt + 1;
@@ -261,7 +320,7 @@ int launch_mfe(const uint8_t *d_seqs, int n, int W, int32_t *d_out, hipStream_t 
     else sf_fast_geometry(W, g.n_cu, n, &grid, &threads, &lds, &scratch_bytes);
     rc = ensure(g.fast_scratch, scratch_bytes);
     if (rc) return rc;
-    HIPCHK(hipEventRecord(e0, st));
+    if ((rc = prof.begin(st))) return rc;
     if (pk)
       sf_pk_launch(grid, W, lds, st, d_seqs, n, W, (const SfDevParams *)g.dP, (const SfFastParams *)g.dF,
                    (int16_t *)g.fast_scratch.p, d_out, d_cnt, d_list, trace_stride, d_db, (int *)g.status.p);
@@ -272,14 +331,26 @@ int launch_mfe(const uint8_t *d_seqs, int n, int W, int32_t *d_out, hipStream_t 
       sf_fast_launch(grid, threads, lds, st, d_seqs, n, W, (const SfDevParams *)g.dP, (const SfFastParams *)g.dF,
                      (int16_t *)g.fast_scratch.p, d_out, d_cnt, d_list, trace_stride, d_db, (int *)g.status.p);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(e1, st));
+    if ((rc = prof.end(st))) return rc;
     // folds that left the int16 range are redone exactly
     rc = launch_full(d_seqs, d_list, d_cnt, n, 1, 1, W, d_out, d_db, d_db ? trace_stride : 0, st);
   }
-  g.ev.push_back({e0, e1});
-  g.prof_launches++;
-  g.prof_folds += n;
+  if (g.prof_on) {
+    g.prof_launches++;
+    g.prof_folds += n;
+  }
   return rc;
+}
+
+// Read the sticky traceback status word after everything queued on `st` (nullptr: the whole device) has finished,
+// and clear it.  Non-zero means a traceback found no decomposition: SF_ERR_INTERNAL.
+int read_status(hipStream_t st, bool whole_device) {
+  int v = 0;
+  if (whole_device) HIPCHK(hipDeviceSynchronize());
+  else HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(hipMemcpy(&v, g.status.p, sizeof(int), hipMemcpyDeviceToHost));
+  if (v) HIPCHK(hipMemset(g.status.p, 0, sizeof(int)));
+  return v ? SF_ERR_INTERNAL : SF_OK;
 }
 
 }  // namespace
@@ -322,6 +393,11 @@ int sf_init(int device_ordinal) {
   HIPCHK(hipMalloc((void **)&g.dP, sizeof(SfDevParams)));
   HIPCHK(hipMalloc((void **)&g.dX, sizeof(SfDevParamsPF)));
   HIPCHK(hipMalloc((void **)&g.dF, sizeof(SfFastParams)));
+  {  // the sticky device status word every traceback ORs into (read and cleared by read_status)
+    int rc = ensure(g.status, sizeof(int));
+    if (rc) return rc;
+    HIPCHK(hipMemset(g.status.p, 0, sizeof(int)));
+  }
   HIPCHK(sf_fast_configure());
   HIPCHK(sf_pfl_configure());
   HIPCHK(sf_pk_configure());
@@ -420,18 +496,13 @@ int sf_mfe_trace_batch(const uint8_t *seqs, int n, int W, int32_t *mfe_out, char
   if ((rc = ensure(g.seqs, (size_t)n * W))) return rc;
   if ((rc = ensure(g.energies, (size_t)n * sizeof(int32_t)))) return rc;
   if ((rc = ensure(g.db, (size_t)n * (W + 1)))) return rc;
-  if ((rc = ensure(g.status, sizeof(int)))) return rc;
-  HIPCHK(hipMemsetAsync(g.status.p, 0, sizeof(int), g.stream));
   HIPCHK(hipMemcpyAsync(g.seqs.p, seqs, (size_t)n * W, hipMemcpyHostToDevice, g.stream));
   if ((rc = launch_mfe((const uint8_t *)g.seqs.p, n, W, (int32_t *)g.energies.p, g.stream, 1, (char *)g.db.p)))
     return rc;
-  int st = 0;
   if (mfe_out)
     HIPCHK(hipMemcpyAsync(mfe_out, g.energies.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, g.stream));
   HIPCHK(hipMemcpyAsync(db_out, g.db.p, (size_t)n * (W + 1), hipMemcpyDeviceToHost, g.stream));
-  HIPCHK(hipMemcpyAsync(&st, g.status.p, sizeof(int), hipMemcpyDeviceToHost, g.stream));
-  HIPCHK(hipStreamSynchronize(g.stream));
-  return st ? SF_ERR_INTERNAL : SF_OK;
+  return read_status(g.stream, false);
 }
 
 int sf_pf_batch(const uint8_t *seqs, int n, int W, double *ens_dG, double *mbd, char *centroid, double *cdist) {
@@ -535,15 +606,12 @@ int sf_scan(const uint8_t *transcript, int L, int W, int step, int win_begin, in
   if ((rc = ensure(g.db, (size_t)n_win * (W + 1)))) return rc;
   if ((rc = ensure(g.cen, (size_t)n_win * (W + 1)))) return rc;
   if ((rc = ensure(g.dbl, (size_t)n_win * 2 * sizeof(double)))) return rc;
-  if ((rc = ensure(g.status, sizeof(int)))) return rc;
   double *d_div = (double *)g.dbl.p, *d_dG = d_div + n_win;
-  HIPCHK(hipMemsetAsync(g.status.p, 0, sizeof(int), g.stream));
   HIPCHK(hipMemcpyAsync(g.transcript.p, transcript, (size_t)L, hipMemcpyHostToDevice, g.stream));
   rc = sf_scan_dev((const uint8_t *)g.transcript.p, L, W, step, win_begin, n_win, r, kind, seed, flags,
                    (int32_t *)g.energies.p, structure ? (char *)g.db.p : nullptr, centroid ? (char *)g.cen.p : nullptr,
                    ens_div ? d_div : nullptr, ens_dG ? d_dG : nullptr, g.stream);
   if (rc) return rc;
-  int st = 0;
   HIPCHK(hipMemcpyAsync(energies, g.energies.p, ne * sizeof(int32_t), hipMemcpyDeviceToHost, g.stream));
   if (structure && !(flags & SF_SCAN_NO_TRACE))
     HIPCHK(hipMemcpyAsync(structure, g.db.p, (size_t)n_win * (W + 1), hipMemcpyDeviceToHost, g.stream));
@@ -552,9 +620,12 @@ int sf_scan(const uint8_t *transcript, int L, int W, int step, int win_begin, in
     if (ens_div) HIPCHK(hipMemcpyAsync(ens_div, d_div, n_win * sizeof(double), hipMemcpyDeviceToHost, g.stream));
     if (ens_dG) HIPCHK(hipMemcpyAsync(ens_dG, d_dG, n_win * sizeof(double), hipMemcpyDeviceToHost, g.stream));
   }
-  HIPCHK(hipMemcpyAsync(&st, g.status.p, sizeof(int), hipMemcpyDeviceToHost, g.stream));
-  HIPCHK(hipStreamSynchronize(g.stream));
-  return st ? SF_ERR_INTERNAL : SF_OK;
+  return read_status(g.stream, false);
+}
+
+int sf_last_status(void) {
+  if (!g.init) return SF_ERR_NOT_INIT;
+  return read_status(nullptr, true);
 }
 
 int sf_set_max_bp_span(int span) {
@@ -594,23 +665,23 @@ int sf_prof_reset(void) {
   g.prof_ms = 0.0;
   g.prof_launches = 0;
   g.prof_folds = 0;
+  g.prof_on = true;  // from now on launch_mfe brackets the dominant kernel with two events
   return SF_OK;
 }
 
 int sf_prof_get(double *ms, int64_t *launches, int64_t *folds) {
   if (!g.init) return SF_ERR_NOT_INIT;
   HIPCHK(hipDeviceSynchronize());
-  for (auto &e : g.ev) {
-    float t = 0.f;
-    HIPCHK(hipEventElapsedTime(&t, e.first, e.second));
-    g.prof_ms += t;
-    hipEventDestroy(e.first);
-    hipEventDestroy(e.second);
-  }
-  g.ev.clear();
+  ProfPair::prof_drain();
   if (ms) *ms = g.prof_ms;
   if (launches) *launches = g.prof_launches;
   if (folds) *folds = g.prof_folds;
+  return SF_OK;
+}
+
+int sf_prof_stop(void) {
+  if (!g.init) return SF_ERR_NOT_INIT;
+  g.prof_on = false;
   return SF_OK;
 }
 

@@ -39,14 +39,16 @@ def pack_records(xp, W, r, energies, structure, centroid, ens_div, ens_dG, n_pad
     n = energies.shape[0]
     if xp.__name__ == "torch":
         rec = xp.zeros((n_pad, lay["size"]), dtype=xp.uint8, device=energies.device)
-        as_u8 = lambda t: t.contiguous().view(xp.uint8).reshape(n, -1)
+        as_u8 = lambda t, width: t.contiguous().view(xp.uint8).reshape(n, width)
     else:
         rec = xp.zeros((n_pad, lay["size"]), dtype=xp.uint8)
-        as_u8 = lambda t: xp.ascontiguousarray(t).view(xp.uint8).reshape(n, -1)
+        as_u8 = lambda t, width: xp.ascontiguousarray(t).view(xp.uint8).reshape(n, width)
+    if n == 0:  # an empty shard (more ranks than windows): nothing to copy, the padding is the record
+        return rec
     for key, arr in (("energies", energies), ("structure", structure), ("centroid", centroid),
                      ("ens_div", ens_div), ("ens_dG", ens_dG)):
         lo, hi = lay[key]
-        rec[:n, lo:hi] = as_u8(arr)
+        rec[:n, lo:hi] = as_u8(arr, hi - lo)
     return rec
 
 
@@ -61,11 +63,12 @@ def unpack_records(rec, W, r, n):
                 ens_dG=get("ens_dG").view(np.float64).reshape(n))
 
 
-def gather_records(local_rec, world):
-    """One all-gather of the equal-sized shards; returns the [world*n_pad, size] tensor on every rank."""
+def gather_records(local_rec, world, force=False):
+    """One all-gather of the equal-sized shards; returns the [world*n_pad, size] tensor on every rank.
+    With one rank nothing is exchanged unless `force` (bench.py's single-rank check of the RCCL path)."""
     import torch
     import torch.distributed as dist
-    if world == 1:
+    if world == 1 and not force:
         return local_rec
     out = torch.empty((world * local_rec.shape[0], local_rec.shape[1]), dtype=torch.uint8, device=local_rec.device)
     dist.all_gather_into_tensor(out, local_rec.contiguous())

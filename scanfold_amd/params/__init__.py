@@ -175,6 +175,29 @@ def load_par(path):
         return parse_par_text(f.read(), source=path)
 
 
+def is_reconstructed(paramset):
+    """True for the set shipped with this package and anything derived from it (random_params keeps the source tag)."""
+    return "recon" in os.path.basename(str(paramset.source))
+
+
+_warned = False
+
+
+def warn_if_reconstructed(paramset, stream=None):
+    """One line on stderr per process when folds run on the reconstructed table: its int11 / int21 / int22 entries are
+    rule-generated and its small tables were typed from memory (tools/make_recon_par.py), so energies, structures and
+    z-scores differ from ViennaRNA's for windows with 1x1, 2x1 or 2x2 interior loops."""
+    global _warned
+    import sys
+    if is_reconstructed(paramset) and not _warned:
+        _warned = True
+        print("scanfold_amd: WARNING energy parameters = %s, a RECONSTRUCTION of Turner 2004, not ViennaRNA's "
+              "rna_turner2004.par: results are not comparable with ViennaRNA-backed ScanFold output.  Use "
+              "--params <rna_turner2004.par> (or params.load_par) for published parameters." % paramset.source,
+              file=stream or sys.stderr)
+    return is_reconstructed(paramset)
+
+
 _default = None
 
 

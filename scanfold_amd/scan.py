@@ -1,4 +1,8 @@
-"""ScanFold-Scan on the HIP engine: same command line, same output file, same TSV bytes.
+"""ScanFold-Scan on the HIP engine: same command line, same output file name, same TSV layout and rounding.
+
+The numbers in the file are those of the loaded energy-parameter set.  The set shipped with this package is a
+RECONSTRUCTION of Turner 2004 (scanfold_amd/params, tools/make_recon_par.py), not ViennaRNA's own table: a run
+with it prints a warning, and `--require-published-params` refuses to run without `--params <rna_turner2004.par>`.
 
 Restates the driver half of /root/reference/ScanFold-Scan.py:
   flags and defaults                     :31-62   (-i -s -w -r -t -type -p --print_random -c)
@@ -17,6 +21,7 @@ temperatures other than the parameter set's are rejected instead of silently hal
 (SURVEY.md F8), and extra flags --seed/--params/--shuffle-backend/-o exist.
 """
 import argparse
+import os
 import sys
 
 import numpy as np
@@ -78,31 +83,86 @@ def format_row(start_nucleotide, end_nucleotide, temperature, MFE, zscore, pscor
             + str(centroid) + "\n")
 
 
+def _text_rows(x, W):
+    """structures / centroids as a list of W-char str: from a list of str, or a uint8 array (n, >= W)."""
+    if isinstance(x, np.ndarray):
+        big = np.ascontiguousarray(x[:, :W]).tobytes().decode("ascii")
+        return [big[k * W:(k + 1) * W] for k in range(x.shape[0])]
+    return x
+
+
 def rows_from_results(seq, starts, W, r, temperature, energies_dcal, structures, centroids, ens_div):
-    """TSV rows for the given windows from raw engine output; rounding exactly as the reference does it."""
+    """TSV rows for the given windows from raw engine output; rounding exactly as the reference does it
+    (ScanFold-Scan.py:386,389,426-433,442).  No per-row numpy objects: the columns are rounded and converted to
+    text as whole lists (np.round on a vector equals round() on each np.float64, str(float) equals
+    str(np.float64) — tests/test_golden_host.py), then joined."""
     E = dcal_to_float(energies_dcal)  # (n, r+1) python-float values of the C floats
     z, sd0 = sfn.zscores_rows(E, r)
     p = sfn.pscores_rows(E)
-    rows = []
-    for k, i in enumerate(starts):
-        frag = transcribe(seq[i:i + W])
-        if frag == ALL_N_120:
-            rows.append(format_row(i + 1, i + W, temperature, int(0.0), "#DIV/0", int(0.0), int(0.0), frag,
-                                   DOTS_120, DOTS_120))
-            continue
-        MFE = round(float(E[k, 0]), 2)
-        if sd0[k]:
-            zscore = "#DIV/0!"
-        else:
-            zscore = round(np.float64(z[k]), 2)  # np.float64.__round__, as upstream's np.mean-derived value
-        pscore = round(float(p[k]), 2)
-        ED = round(float(ens_div[k]), 2)
-        rows.append(format_row(i + 1, i + W, temperature, MFE, zscore, pscore, ED, frag, structures[k], centroids[k]))
+    tseq = transcribe(seq)
+    n = len(starts)
+    t = str(temperature)
+    mfe_s = [str(round(v, 2)) for v in E[:, 0].tolist()]
+    z_s = [str(v) for v in np.round(z, 2).tolist()]  # np.float64.__round__, as upstream's np.mean-derived value
+    if sd0.any():
+        for k in np.nonzero(sd0)[0].tolist():
+            z_s[k] = "#DIV/0!"
+    p_s = [str(round(v, 2)) for v in p.tolist()]
+    ed_s = [str(round(v, 2)) for v in np.asarray(ens_div, dtype=np.float64).tolist()]
+    structures = _text_rows(structures, W)
+    centroids = _text_rows(centroids, W)
+    rows = ["%d\t%d\t%s\t%s\t%s\t%s\t%s\t%s\t%s\t%s\n" % (i + 1, i + W, t, mfe_s[k], z_s[k], p_s[k], ed_s[k],
+                                                            tseq[i:i + W], structures[k], centroids[k])
+            for k, i in enumerate(starts)]
+    if ALL_N_120 in tseq:  # the reference's literal 120 x 'N' shortcut (ScanFold-Scan.py:374-380)
+        for k, i in enumerate(starts):
+            if tseq[i:i + W] == ALL_N_120:
+                rows[k] = format_row(i + 1, i + W, temperature, int(0.0), "#DIV/0", int(0.0), int(0.0), ALL_N_120,
+                                     DOTS_120, DOTS_120)
+    assert len(rows) == n
     return rows
 
 
+CHUNK_WINDOWS = 4096  # windows per engine call: the host formats chunk k while the GPU computes chunk k+1
+
+
+def _engine_chunks(eng, seq, W, step, n_win, r, kind, seed, lo=0, hi=None, chunk=None, threaded=True):
+    """Yield (w0, result) for consecutive chunks of windows [lo, hi).  The engine calls run on a helper thread
+    (ctypes drops the GIL for the duration of sf_scan), so the caller's work on chunk k overlaps chunk k+1 on
+    the GPU.  Only that thread talks to the library while the generator is alive."""
+    import queue
+    import threading
+    hi = n_win if hi is None else hi
+    chunk = chunk or int(os.environ.get("SCANFOLD_CHUNK_WINDOWS", CHUNK_WINDOWS))
+    bounds = [(w0, min(chunk, hi - w0)) for w0 in range(lo, hi, chunk)]
+    if not threaded or len(bounds) <= 1:
+        for w0, nw in bounds:
+            yield w0, eng.scan(seq, W, step, w0, nw, r, kind, seed, raw=True)
+        return
+    q = queue.Queue(maxsize=2)
+
+    def produce():
+        try:
+            for w0, nw in bounds:
+                q.put((w0, eng.scan(seq, W, step, w0, nw, r, kind, seed, raw=True)))
+        except BaseException as e:  # hand the error to the consumer
+            q.put((None, e))
+        q.put((None, None))
+
+    th = threading.Thread(target=produce, daemon=True)
+    th.start()
+    while True:
+        w0, res = q.get()
+        if w0 is None:
+            th.join()
+            if res is not None:
+                raise res
+            return
+        yield w0, res
+
+
 def scan_record(seq, W, step, r, shuffle_type, temperature=37, engine=None, seed=0, shuffle_backend="device",
-                print_random=False):
+                print_random=False, chunk=None):
     """All windows of one record -> list of TSV row strings."""
     eng = engine if engine is not None else _lib.get_engine()
     if float(int(temperature)) != eng.params.temperature:
@@ -114,25 +174,45 @@ def scan_record(seq, W, step, r, shuffle_type, temperature=37, engine=None, seed
     starts = window_starts(len(seq), W, step)
     n_win = len(starts)
     kind = _lib.SHUFFLE_DI if shuffle_type == "di" else _lib.SHUFFLE_MONO
-    if shuffle_backend == "device":
-        res = eng.scan(seq, W, step, 0, n_win, r, kind, seed)
-        energies_dcal = res["energies"]
-    elif shuffle_backend == "python":
-        # the reference's own generators on the host (random module), folds still batched on the device
-        res = eng.scan(seq, W, step, 0, n_win, 0, kind, seed)
-        rows_seq = []
-        for i in starts:
-            frag = transcribe(seq[i:i + W])
-            rows_seq.append(frag)
-            rows_seq.extend(sfn.scramble(frag, r, shuffle_type))
-        energies_dcal = eng.mfe_batch(rows_seq).reshape(n_win, r + 1)
-    else:
+    if shuffle_backend not in ("device", "python"):
         raise ValueError("shuffle_backend must be 'device' or 'python'")
-    if print_random:
-        for k in range(n_win):
-            print([float(v) for v in dcal_to_float(energies_dcal[k])])
-    return rows_from_results(seq, starts, W, r, temperature, energies_dcal, res["structure"], res["centroid"],
-                             res["ens_div"])
+    rows = []
+    for w0, res in _engine_chunks(eng, seq, W, step, n_win, r if shuffle_backend == "device" else 0, kind, seed,
+                                  chunk=chunk, threaded=(shuffle_backend == "device")):
+        sub = starts[w0:w0 + len(res["ens_div"])]
+        energies_dcal = res["energies"]
+        if shuffle_backend == "python":
+            # the reference's own generators on the host (random module), folds still batched on the device
+            rows_seq = []
+            for i in sub:
+                frag = transcribe(seq[i:i + W])
+                rows_seq.append(frag)
+                rows_seq.extend(sfn.scramble(frag, r, shuffle_type))
+            energies_dcal = eng.mfe_batch(rows_seq).reshape(len(sub), r + 1)
+        if print_random:
+            for k in range(len(sub)):
+                print([float(v) for v in dcal_to_float(energies_dcal[k])])
+        rows.extend(rows_from_results(seq, sub, W, r, temperature, energies_dcal, res["structure"], res["centroid"],
+                                      res["ens_div"]))
+    return rows
+
+
+def scan_record_sharded(seq, W, step, r, shuffle_type, temperature, eng, seed, rank, world):
+    """One record over `world` ranks (one process per GPU): contiguous window ranges, ONE all-gather of the
+    fixed-size records (scanfold_amd/dist.py), rows formatted on every rank (rank 0 writes them)."""
+    import torch
+    from . import dist as sdist
+    starts = window_starts(len(seq), W, step)
+    n_win = len(starts)
+    kind = _lib.SHUFFLE_DI if shuffle_type == "di" else _lib.SHUFFLE_MONO
+    dev = torch.device("cuda", eng.device)
+
+    def produce(lo, hi):
+        res = eng.scan(seq, W, step, lo, hi - lo, r, kind, seed, raw=True)
+        return tuple(torch.from_numpy(res[k]).to(dev) for k in ("energies", "structure", "centroid", "ens_div", "ens_dG"))
+
+    m = sdist.scan_sharded(produce, n_win, W, r, rank, world, torch)
+    return rows_from_results(seq, starts, W, r, temperature, m["energies"], m["structure"], m["centroid"], m["ens_div"])
 
 
 def build_parser():
@@ -151,42 +231,92 @@ def build_parser():
     parser.add_argument('--seed', type=int, default=0, help='seed of the device shuffle generator')
     parser.add_argument('--shuffle-backend', choices=("device", "python"), default="device")
     parser.add_argument('--params', type=str, default=None, help='ViennaRNA .par (v2.0) file to use')
+    parser.add_argument('--require-published-params', action='store_true',
+                        help='refuse to run on the reconstructed default parameter set (needs --params)')
+    parser.add_argument('--gpus', type=int, default=1, help='shard the windows of every record over this many GPUs '
+                        '(one process per GPU, one RCCL all-gather per record)')
     parser.add_argument('-o', '--output', type=str, default=None, help='output path (default: upstream naming)')
     return parser
 
 
+def _relaunch_sharded(args_list, gpus):
+    """`--gpus N` from a plain `python -m scanfold_amd.scan`: start N ranks under torch.distributed.run as a CHILD
+    process (never exec: nothing here has touched the GPU yet, and nothing may replace a process that has) and
+    return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), "-m", "scanfold_amd.scan"] + list(args_list)
+    return subprocess.run(cmd).returncode
+
+
 def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     args = build_parser().parse_args(argv)
     if not args.filename:
         raise SystemExit("-i/--filename is required")
     if args.constraints is not None:
         raise NotImplementedError("hard constraints (-c) are not supported by the HIP engine yet")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return _relaunch_sharded(argv, args.gpus)
     window_size, step_size, randomizations = int(args.w), int(args.s), int(args.r)
     temperature, shuffle_type = int(args.t), str(args.type)
     out_path = args.output or (args.filename + ".forward.win_" + str(window_size) + ".stp_" + str(step_size)
                                + ".rnd_" + str(randomizations) + ".shfl_" + str(shuffle_type) + ".txt")
+    from . import params as _params
+    if args.require_published_params and not args.params:
+        raise SystemExit("--require-published-params: give --params <path to ViennaRNA's rna_turner2004.par>; the "
+                         "shipped default (%s) is a reconstruction" % _params.DEFAULT_PAR)
     eng = _lib.get_engine()
     eng.set_max_bp_span(args.span)
     if args.params:
-        from . import params as _params
         eng.load_params(_params.load_par(args.params))
+    if rank == 0:
+        _params.warn_if_reconstructed(eng.params)
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        if args.shuffle_backend != "device":
+            raise SystemExit("--gpus > 1 needs the device shuffle generator")
+        torch.cuda.set_device(eng.device)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", eng.device))
     if args.shuffle_backend == "python":
         import random
         random.seed(args.seed)
-    with open(out_path, 'w') as w:
+    w = open(out_path, 'w') if rank == 0 else None
+    try:
         for read_name, seq in read_fasta(args.filename):
-            print("Scanning sequence " + str(read_name) + "\nSequence Length: " + str(len(seq)) + "nt long.")
+            if rank == 0:
+                print("Scanning sequence " + str(read_name) + "\nSequence Length: " + str(len(seq)) + "nt long.")
             if len(seq) < window_size:
                 continue
+            if world > 1:
+                rows = scan_record_sharded(seq, window_size, step_size, randomizations, shuffle_type, temperature,
+                                           eng, args.seed, rank, world)
+            else:
+                rows = scan_record(seq, window_size, step_size, randomizations, shuffle_type, temperature, eng,
+                                   seed=args.seed, shuffle_backend=args.shuffle_backend,
+                                   print_random=(args.print_random == "on"))
+            if rank != 0:
+                continue
             w.write(header_line(read_name))
-            rows = scan_record(seq, window_size, step_size, randomizations, shuffle_type, temperature, eng,
-                               seed=args.seed, shuffle_backend=args.shuffle_backend,
-                               print_random=(args.print_random == "on"))
-            for row in rows:
-                if args.print_to_screen:
+            if args.print_to_screen:
+                for row in rows:
                     f = row.rstrip("\n").split("\t")
                     print("\t".join(f[:7]) + "\n" + f[7] + "\n" + f[8] + "\n" + f[9] + "\n")
-                w.write(row)
+            w.writelines(rows)
+    finally:
+        if w is not None:
+            w.close()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            dist.destroy_process_group()
     return 0
 
 

@@ -10,8 +10,16 @@ for p in (ROOT, os.path.join(ROOT, "tests", "emul")):
         sys.path.insert(0, p)
 
 
+SUMMARY_LINES = []  # one-line findings a test wants in the terminal summary even under -q (e.g. "VIENNA: absent")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+
+
+def pytest_terminal_summary(terminalreporter):
+    for line in SUMMARY_LINES:
+        terminalreporter.write_line(line)
 
 
 @pytest.fixture(scope="session")

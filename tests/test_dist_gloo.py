@@ -6,6 +6,7 @@ import sys
 import textwrap
 
 import numpy as np
+import pytest
 
 from scanfold_amd import dist as sdist
 
@@ -48,7 +49,7 @@ WORKER = textwrap.dedent("""
     from test_dist_gloo import fake_records
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    W, r, n_win = 24, 5, 11   # 11 windows over 2 ranks: ragged last shard
+    W, r, n_win = 24, 5, int(os.environ["N_WIN"])   # 11 windows over 2 ranks: ragged last shard; 1 or 5 over 2 or 4: empty shards
     def produce(lo, hi):
         return tuple(torch.from_numpy(np.ascontiguousarray(a)) for a in fake_records(lo, hi, W, r))
     out = sdist.scan_sharded(produce, n_win, W, r, rank, world, torch)
@@ -60,14 +61,59 @@ WORKER = textwrap.dedent("""
 """)
 
 
-def test_two_rank_gather_over_gloo(tmp_path):
-    script = tmp_path / "worker.py"
-    script.write_text(WORKER % {"root": ROOT})
+def run_ranks(script, nproc, env=None, timeout=300):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                          "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
-                         capture_output=True, text=True, timeout=300, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % nproc,
+                           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+                          capture_output=True, text=True, timeout=timeout,
+                          env=dict(os.environ, OMP_NUM_THREADS="1", **(env or {})))
+
+
+@pytest.mark.parametrize("nproc,n_win", [(2, 11), (2, 1), (4, 5)])
+def test_gather_over_gloo_ragged_and_empty_shards(tmp_path, nproc, n_win):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT})
+    out = run_ranks(script, nproc, {"N_WIN": str(n_win)})
     assert out.returncode == 0, out.stderr[-2000:]
-    assert "RANK0_OK=True" in out.stdout and "RANK1_OK=True" in out.stdout, out.stdout + out.stderr[-1000:]
+    for rank in range(nproc):
+        assert "RANK%d_OK=True" % rank in out.stdout, out.stdout + out.stderr[-1000:]
+
+
+ENGINE_WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, %(root)r)
+    sys.path.insert(0, os.path.join(%(root)r, "tests", "emul"))
+    import numpy as np, torch, torch.distributed as dist
+    from scanfold_amd import dist as sdist, scan as scanmod, _lib
+    from scanfold_amd._lib import Engine
+    from emul_engine import EMUL_LIB
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    eng = Engine(device=0, lib_path=EMUL_LIB)      # the kernel sources compiled for the CPU (test only)
+    seq = "".join("ACGU"[k] for k in np.random.default_rng(5).integers(0, 4, 75))
+    W, step, r, seed = 30, 4, 3, 9
+    starts = scanmod.window_starts(len(seq), W, step)
+    def produce(lo, hi):
+        res = eng.scan(seq, W, step, lo, hi - lo, r, _lib.SHUFFLE_DI, seed, raw=True)
+        return tuple(torch.from_numpy(res[k]) for k in ("energies", "structure", "centroid", "ens_div", "ens_dG"))
+    m = sdist.scan_sharded(produce, len(starts), W, r, rank, world, torch)
+    rows = scanmod.rows_from_results(seq, starts, W, r, 37, m["energies"], m["structure"], m["centroid"], m["ens_div"])
+    whole = scanmod.scan_record(seq, W, step, r, "di", 37, eng, seed=seed)
+    print("RANK%%d_ROWS_EQUAL=%%s n=%%d" %% (rank, rows == whole, len(rows)))
+    dist.destroy_process_group()
+""")
+
+
+def test_engine_scan_sharded_over_two_gloo_ranks_equals_single_process(tmp_path):
+    """The real engine code (kernel sources compiled for the CPU, tests/emul) behind dist.scan_sharded on two gloo ranks:
+    the merged TSV rows equal the single-process scan — a window's shuffles depend on its absolute index only."""
+    from emul_engine import build
+    build()
+    script = tmp_path / "engine_worker.py"
+    script.write_text(ENGINE_WORKER % {"root": ROOT})
+    out = run_ranks(script, 2, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "RANK0_ROWS_EQUAL=True n=12" in out.stdout and "RANK1_ROWS_EQUAL=True n=12" in out.stdout, \
+        out.stdout + out.stderr[-1500:]

@@ -133,3 +133,38 @@ def test_fasta_reader(tmp_path):
     p.write_text(">rec1 some description\nACGT\nacgu\n\n>rec2\nGG GG\n")
     assert scanmod.read_fasta(str(p)) == [("rec1", "ACGTacgu"), ("rec2", "GGGG")]
     assert scanmod.transcribe("ACGTacgt") == "ACGUacgu"
+
+
+def test_vectorised_rows_equal_the_per_row_reference_expressions():
+    """rows_from_results builds whole columns at once; every row must still be what the reference's per-window
+    expressions give (ScanFold-Scan.py:386,389,426-433,442, restated here with the per-row functions that
+    tests above pin to the reference): 4 000 windows incl. sd == 0, ties, halfway values, uint8-array text input."""
+    rng = np.random.default_rng(12)
+    n, W, r = 4000, 30, 20
+    seq = "".join("ACGT"[k] for k in rng.integers(0, 4, n + W - 1))
+    dcal = rng.integers(-3000, 100, (n, r + 1)).astype(np.int32)
+    dcal[5] = -1230                      # sd == 0
+    dcal[6, 1:] = dcal[6, 0]             # sd == 0 again
+    dcal[7, 1:] = dcal[7, 0] + 5         # every shuffle above the native: p == 0
+    dcal[8] = np.arange(r + 1) * 5 - 25  # regular spacing: halfway-ish z values
+    ed = np.round(rng.uniform(0, 40, n), 3)
+    ed[:50] = np.arange(50) / 8.0 + 0.005
+    db = np.frombuffer(b".()", dtype=np.uint8)[rng.integers(0, 3, (n, W + 1))]
+    cen = np.frombuffer(b".()", dtype=np.uint8)[rng.integers(0, 3, (n, W + 1))]
+    starts = list(range(n))
+    got = scanmod.rows_from_results(seq, starts, W, r, 37, dcal, db, cen, ed)
+    E = scanmod.dcal_to_float(dcal)
+    for k in list(range(60)) + list(range(60, n, 37)):
+        el = [float(v) for v in E[k]]
+        MFE = round(el[0], 2)
+        try:
+            zscore = round(sfn.zscore_function(el, r), 2)
+        except Exception:
+            zscore = sfn.zscore_function(el, r)
+        pscore = round(sfn.pscore_function(el, r), 2)
+        ED = round(float(ed[k]), 2)
+        frag = seq[k:k + W].replace("T", "U")
+        exp = scanmod.format_row(k + 1, k + W, 37, MFE, zscore, pscore, ED, frag, bytes(db[k, :W]).decode(),
+                                 bytes(cen[k, :W]).decode())
+        assert got[k] == exp, k
+    assert got[5].split("\t")[4] == "#DIV/0!"

@@ -148,6 +148,40 @@ def test_device_shuffles_preserve_the_reference_invariants(gpu_engine):
         assert (ascii_rows(other)[1] != rows[1]).any()  # the seed matters
 
 
+def test_device_shuffle_equals_the_shuffle_oracle_bit_for_bit(gpu_engine, oracle):
+    """sf_shuffle_kernel vs oracle/sf_shuffle_oracle.c (the reference's algorithm, ScanFold-Scan.py:87-209,248-250,
+    on the product's Philox stream): cfg1, cfg2 and 10 000 random windows that contain N."""
+    cases = [(synth_transcript(1000, 1), 120, 40, 0, 23, 10, 3), (synth_transcript(10000, 2), 120, 10, 0, 989, 30, 11)]
+    rng = np.random.default_rng(44)
+    trn = "".join("ACGUNt"[k] for k in rng.choice(6, 10119, p=[0.24, 0.24, 0.24, 0.24, 0.03, 0.01]))
+    cases += [(trn, 120, 1, 0, 10000, 3, 2 ** 41 + 7), (trn, 200, 37, 5, 200, 7, 1), (trn, 16, 3, 0, 700, 2, 6)]
+    for kind in (_lib.SHUFFLE_MONO, _lib.SHUFFLE_DI):
+        for (tr, W, step, wb, nw, r, seed) in cases:
+            dev = gpu_engine.shuffle_windows(tr, W, step, wb, nw, r, kind, seed)
+            assert (dev == oracle.shuffle_windows(tr, W, step, wb, nw, r, kind, seed)).all(), (kind, W, step)
+
+
+def test_device_di_shuffle_is_uniform_over_the_enumerated_set(gpu_engine):
+    """The distribution that decides every z-score: on short inputs the device dinucleotide shuffle must be uniform over
+    the exhaustively enumerated set of admissible sequences, and indistinguishable from the histogram of the
+    reference's own dinuclShuffle (tests/golden/reference_dinucl_hist.json, 30 000 reference draws per input)."""
+    from shuffle_util import chi2_limit, chi2_two_sample, chi2_uniform, codes_to_str, di_arrangements
+    items = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_dinucl_hist.json")))["items"]
+    for k, it in enumerate(items):
+        s = it["s"]
+        allowed = di_arrangements(s)
+        rows = codes_to_str(gpu_engine.shuffle_windows(s, len(s), 1, 0, 1, 50000, _lib.SHUFFLE_DI, 900 + k))
+        hist = Counter(rows[1:])
+        assert sorted(hist) == allowed, s
+        assert chi2_uniform([hist[a] for a in allowed]) < chi2_limit(len(allowed) - 1), s
+        assert chi2_two_sample([hist[a] for a in allowed], [it["hist"][a] for a in allowed]) < chi2_limit(
+            len(allowed) - 1), s
+    # mono: uniform over the 60 distinct permutations of a 5-mer with one repeated letter
+    rows = codes_to_str(gpu_engine.shuffle_windows("ACGUA", 5, 1, 0, 1, 60000, _lib.SHUFFLE_MONO, 5))[1:]
+    hist = Counter(rows)
+    assert len(hist) == 60 and chi2_uniform(list(hist.values())) < chi2_limit(59)
+
+
 def test_mono_shuffle_is_close_to_uniform(gpu_engine):
     tr = "ACGU" * 5
     rows = gpu_engine.shuffle_windows(tr, 20, 1, 0, 1, 20000, _lib.SHUFFLE_MONO, 1)[1:]
@@ -157,7 +191,7 @@ def test_mono_shuffle_is_close_to_uniform(gpu_engine):
 
 def build_expected_rows(oracle, eng, seq, W, step, r, kind, seed):
     starts = scanmod.window_starts(len(seq), W, step)
-    rows = ascii_rows(eng.shuffle_windows(seq, W, step, 0, len(starts), r, kind, seed))
+    rows = ascii_rows(oracle.shuffle_windows(seq, W, step, 0, len(starts), r, kind, seed))  # oracle shuffles too
     E = oracle.mfe_batch(rows).reshape(len(starts), r + 1)
     structs, cens, eds = [], [], []
     for i in starts:
@@ -222,6 +256,44 @@ def test_config3_size_independent_properties(gpu_engine, oracle):
     # (e) idempotence
     again = gpu_engine.scan(seq, W, 1, lo, n, r, _lib.SHUFFLE_DI, 17, flags)["energies"]
     assert (again == full).all()
+
+
+def test_bench_instantiation_cfg3_w120_step1_r100_all_outputs(gpu_engine, oracle):
+    """The exact code path bench.py times (BASELINE config 3: W=120, step=1, r=100, di, flags=0: in-kernel traceback
+    of every native row + partition function with inside tables shared between consecutive windows), on three
+    ranges of the 30 kb transcript — its first windows, its last windows, a middle stretch; 2 650 windows, dozens
+    of shared-inside runs and their boundaries.  EVERY window is compared with the oracle (structure, centroid,
+    ensemble diversity, ensemble dG, native energy) and with the stand-alone kernels; all 101 energies of 96
+    windows are compared with the oracle on the oracle's own shuffles.  ScanFold-Scan.py:382-389,419-423."""
+    seq = synth_transcript(30000, 3)
+    W, r, seed = 120, 100, 2026
+    nwin_total = len(seq) - W + 1
+    for lo, n in ((0, 900), (14000, 850), (nwin_total - 900, 900)):
+        res = gpu_engine.scan(seq, W, 1, lo, n, r, _lib.SHUFFLE_DI, seed, 0)
+        wins = [seq[i:i + W] for i in range(lo, lo + n)]
+        # stand-alone kernels on the same windows
+        e1, db1 = gpu_engine.mfe_trace_batch(wins)
+        alone = gpu_engine.pf_batch(wins)
+        assert (res["energies"][:, 0] == e1).all() and res["structure"] == db1
+        assert res["centroid"] == alone["centroid"]
+        assert np.allclose(res["ens_div"], alone["mean_bp_dist"], rtol=1e-12, atol=1e-12)
+        assert np.allclose(res["ens_dG"], alone["dG"], rtol=1e-12, atol=1e-12)
+        # the oracle on every window (one OpenMP thread per window)
+        nat = np.frombuffer("".join(wins).encode(), dtype=np.uint8).reshape(n, W)
+        ref = oracle.scan_windows(nat, n, 0)
+        assert (ref["energies"][:, 0] == res["energies"][:, 0]).all()
+        assert ref["structure"] == res["structure"]
+        assert ref["centroid"] == res["centroid"]
+        assert np.abs(ref["ens_div"] - res["ens_div"]).max() < PF_TOL
+        for w in range(0, n, 50):
+            assert abs(oracle.pf(wins[w])["dG"] - res["ens_dG"][w]) < PF_TOL
+        # all r+1 energies of 32 windows per range, shuffles regenerated by the shuffle oracle
+        for w0 in (0, n // 2, n - 16):
+            rows = ascii_rows(oracle.shuffle_windows(seq, W, 1, lo + w0, 16, r, _lib.SHUFFLE_DI, seed))
+            assert (oracle.mfe_batch(rows).reshape(16, r + 1) == res["energies"][w0:w0 + 16]).all()
+    # the z-score / TSV tail on the first range, against rows built from oracle values only
+    got = scanmod.scan_record(seq[:1019], W, 1, r, "di", 37, gpu_engine, seed=seed)
+    assert got == build_expected_rows(oracle, gpu_engine, seq[:1019], W, 1, r, _lib.SHUFFLE_DI, seed)
 
 
 def test_config5_shape_w200_r1000_slice(gpu_engine, oracle):

@@ -110,10 +110,9 @@ int sf_last_status(void);
  * SURVEY.md 8(f) rank 1, first item; hard constraints and temperatures != 37 C are not implemented. */
 int sf_set_max_bp_span(int span);
 
-/* Diagnostics: 0 = automatic (LDS int16 kernel with int32 fallback), 1 = always the int32 kernel,
- * 2 = the packed two-cells-per-lane LDS kernel for W <= 128 (experimental, slower in round 1),
- * 3 = the two-folds-per-workgroup LDS kernel for W <= 128 (interleaved tables, packed int16).
- * Results are identical in every mode; tests use it to cross-check the kernels. */
+/* Diagnostics: 0 = automatic (LDS int16 kernel with int32 fallback), 1 = always the int32 kernel.
+ * Results are identical in both modes; tests use it to cross-check the kernels.  (Round 1's packed variants,
+ * modes 2 and 3, were slower and have been removed.) */
 int sf_set_kernel_mode(int mode);
 
 /* Measurement support for bench.py: HIP-event time (ms) and launch count of the dominant kernel

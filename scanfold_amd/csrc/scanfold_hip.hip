@@ -16,8 +16,6 @@
 #include "sf_energy.h"
 #include "sf_mfe_full.hip.h"
 #include "sf_mfe_fast.hip.h"
-#include "sf_mfe_pk.hip.h"
-#include "sf_mfe_dual.hip.h"
 #include "sf_pf.hip.h"
 #include "sf_pf_fast.hip.h"
 #include "sf_pf_lds.hip.h"
@@ -50,9 +48,6 @@ struct Ctx {
   int64_t prof_launches = 0, prof_folds = 0;
   int force_full = 0;
   int fast_ok = 0;
-  int mfe_kernel = 0;  // 0: one cell per lane (sf_mfe_fast.hip.h); 1: two cells per lane, packed int16, W <= 128
-                       // (sf_mfe_pk.hip.h; kernel mode 2 or SCANFOLD_MFE_KERNEL=pk); 2: two folds per workgroup with
-                       // interleaved tables (sf_mfe_dual.hip.h; kernel mode 3 or SCANFOLD_MFE_KERNEL=dual)
   int max_bp_span = 0;  // RNA.md().max_bp_span; <= 0: no limit
   int pf_kernel = 0;  // 0: LDS-resident kernel where it fits; 1: device-memory tables (SCANFOLD_PF_KERNEL=global)
   int pf_blocks_per_cu = 4;  // 256 VGPRs per thread: 2 waves per SIMD
@@ -313,22 +308,11 @@ int launch_mfe(const uint8_t *d_seqs, int n, int W, int32_t *d_out, hipStream_t 
     HIPCHK(hipMemsetAsync(d_cnt, 0, sizeof(int), st));
     int grid = 0, threads = 0;
     size_t lds = 0, scratch_bytes = 0;
-    const bool pk = sf_pk_w_supported(W) && g.mfe_kernel == 1;
-    const bool dual = sf_dual_w_supported(W) && g.mfe_kernel == 2;
-    if (pk) sf_pk_geometry(W, g.n_cu, n, &grid, &lds, &scratch_bytes);
-    else if (dual) sf_dual_geometry(W, g.n_cu, n, &grid, &lds, &scratch_bytes);
-    else sf_fast_geometry(W, g.n_cu, n, &grid, &threads, &lds, &scratch_bytes);
+    sf_fast_geometry(W, g.n_cu, n, &grid, &threads, &lds, &scratch_bytes);
     rc = ensure(g.fast_scratch, scratch_bytes);
     if (rc) return rc;
     if ((rc = prof.begin(st))) return rc;
-    if (pk)
-      sf_pk_launch(grid, W, lds, st, d_seqs, n, W, (const SfDevParams *)g.dP, (const SfFastParams *)g.dF,
-                   (int16_t *)g.fast_scratch.p, d_out, d_cnt, d_list, trace_stride, d_db, (int *)g.status.p);
-    else if (dual)
-      sf_dual_launch(grid, W, lds, st, d_seqs, n, W, (const SfDevParams *)g.dP, (const SfFastParams *)g.dF,
-                     (int16_t *)g.fast_scratch.p, d_out, d_cnt, d_list, trace_stride, d_db, (int *)g.status.p);
-    else
-      sf_fast_launch(grid, threads, lds, st, d_seqs, n, W, (const SfDevParams *)g.dP, (const SfFastParams *)g.dF,
+    sf_fast_launch(grid, threads, lds, st, d_seqs, n, W, (const SfDevParams *)g.dP, (const SfFastParams *)g.dF,
                      (int16_t *)g.fast_scratch.p, d_out, d_cnt, d_list, trace_stride, d_db, (int *)g.status.p);
     HIPCHK(hipGetLastError());
     if ((rc = prof.end(st))) return rc;
@@ -400,9 +384,6 @@ int sf_init(int device_ordinal) {
   }
   HIPCHK(sf_fast_configure());
   HIPCHK(sf_pfl_configure());
-  HIPCHK(sf_pk_configure());
-  HIPCHK(sf_dual_configure());
-  if (const char *mk = getenv("SCANFOLD_MFE_KERNEL")) g.mfe_kernel = strcmp(mk, "pk") == 0 ? 1 : (strcmp(mk, "dual") == 0 ? 2 : 0);
   if (const char *pk = getenv("SCANFOLD_PF_KERNEL")) g.pf_kernel = (strcmp(pk, "global") == 0);
   if (const char *ps = getenv("SCANFOLD_PF_SHARE")) g.pf_share_inside = atoi(ps) != 0;
   if (const char *pr = getenv("SCANFOLD_PF_RUN_LEN")) g.pf_run_len = atoi(pr);
@@ -641,9 +622,8 @@ int sf_set_max_bp_span(int span) {
 
 int sf_set_kernel_mode(int mode) {
   if (!g.init) return SF_ERR_NOT_INIT;
-  if (mode < 0 || mode > 3) return SF_ERR_BAD_ARG;
+  if (mode < 0 || mode > 1) return SF_ERR_BAD_ARG;
   g.force_full = (mode == 1);
-  g.mfe_kernel = mode == 2 ? 1 : (mode == 3 ? 2 : 0);
   return SF_OK;
 }
 

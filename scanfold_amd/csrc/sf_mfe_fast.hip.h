@@ -10,7 +10,11 @@
 // incremental (below) with all of its state in registers.
 //
 // LDS per workgroup (W=120: 39.8 kB -> 4 workgroups per CU):
-//   fML   int16 full triangle, diagonal-major          (the O(W^3) multiloop split reads every diagonal)
+//   fML   int16, every diagonal (the O(W^3) multiloop split reads them all).  W <= 128: a triangle, diagonal after
+//         diagonal.  W > 128 (FOLD): folded into a rectangle — diagonal x <= H = (W+3)/2 is the left part of row x-4,
+//         diagonal W+3-x the right part of the same row (their lengths add up to the row length W-3) — so that a
+//         multiloop split walks both operands with constant strides (sf_fast_split_stretch): +6 % at W = 200; at
+//         W = 120 the same change measured -5 % (profiles/r02), so the narrow kernel keeps the triangle
 //   CI, C1N, CB  int16, rolling window of SF_FAST_NR diagonals of c, pre-added with the inner pair's terms:
 //           CI  = c + mismatchI [rtype][S[j+1]][S[i-1]]   generic loops
 //           C1N = c + mismatch1nI[rtype][S[j+1]][S[i-1]]  1 x n loops
@@ -138,6 +142,7 @@ struct SfFastLayout {
 static inline __host__ __device__ SfFastLayout sf_fast_layout(int W) {
   SfFastLayout L;
   int tri = (W - 4) * W - (W * (W - 1) / 2 - 6);  // sum_{d=4}^{W-1} (W-d)
+  if (W > 128) tri = ((W + 3) / 2 - 3) * (W - 3);  // FOLD: (H-3) rows of S = W-3 entries (same area)
   if (tri < 0) tri = 0;
   tri = (tri + 1) & ~1;
   L.tri = tri;
@@ -155,7 +160,8 @@ static inline __host__ __device__ SfFastLayout sf_fast_layout(int W) {
   // 256 bytes per wave, needed while d < 36 only: from W = 96 on they lie in the end of the fML triangle, whose
   // last 45 diagonals (>= 2 kB from W = 96 on, first written at d = W-45 >= 51) are still unused by then
   const int guard_bytes = (W <= 128 ? 4 : 8) * 256;
-  if (W >= 96) L.off_guard = tri * 2 - guard_bytes;
+  if (W > 128) L.off_guard = 32 * (W - 3) * 2;  // FOLD: rows 32.. hold diagonals 36..W-33 only (first written at d = 36)
+  else if (W >= 96) L.off_guard = tri * 2 - guard_bytes;
   else { L.off_guard = o; o += guard_bytes; }
   L.total = o;
   return L;
@@ -174,9 +180,8 @@ struct SfFastCtx {
   const SfFastParams *F;
   int16_t *cg;
   int W, TAU, MLbase, MLclosing, MLintern;
-  int fml_pad;  // 1: every diagonal of the fML triangle starts at an even index (sf_mfe_pk.hip.h)
+  int fold;     // 1: the fML area is the folded rectangle (W > 128), 0: the triangle
   int maxd;     // largest allowed j - i of a base pair (max_bp_span - 1)
-  int fst;      // element stride of fML (2 when two folds are interleaved, sf_mfe_dual.hip.h)
   const int16_t *uNIN, *uIL, *uL1N, *uBUL;  // size-dependent terms, LDS copies (uniform reads)
   int16_t *BN;  // sf_mfe_fast_kernel: the bulge and 1xn rolling tables interleaved, entry x = (CB[x], C1N[x]) in one
                 // 32-bit word (CB / C1N above stay null there); uNIN = [NIN 32][IL 32][(BUL[u], L1N[u-1]) 32 pairs]
@@ -196,6 +201,82 @@ struct SfFastCtx {
 // MI355X as wrong minima in a variant of this kernel.)
 #define SF_UNI(tab, k) ((int)(tab)[k])
 
+// One stretch of a multiloop split (see sf_fast_dml): len terms, term t = pa[t * sa] + pb[t * sb] with
+// sa = AP ? S : -(S-1), sb = BP ? S : -(S-1).  Batches of eight terms whose addresses are base + compile-time offset
+// (a negative stride is addressed from the batch's last term, so every offset is >= 0).  Full batches advance by a
+// constant; the final batch is placed to end exactly at the stretch's last term (it may overlap the one before: a
+// minimum does not mind seeing a term twice).  A stretch shorter than eight terms is ONE batch whose surplus
+// terms repeat the last one, so that all of its reads are in flight together.  len is wave-uniform.
+#ifndef SF_SPLIT_NB
+#define SF_SPLIT_NB 8  // terms per batch = LDS read pairs in flight
+#endif
+template <bool AP, bool BP>
+__device__ __forceinline__ void sf_fast_split_stretch(const int16_t *pa, const int16_t *pb, const int len, const int S,
+                                                      int &dec, int &dec2) {
+  constexpr int NB = SF_SPLIT_NB;
+  const int sa = AP ? S : -(S - 1), sb = BP ? S : -(S - 1);
+  int a[NB], b[NB];
+#define SF_SPLIT_REDUCE()                           \
+  _Pragma("unroll") for (int k = 0; k < NB; k += 2) { \
+    dec = sfd_min(dec, a[k] + b[k]);                \
+    dec2 = sfd_min(dec2, a[k + 1] + b[k + 1]);      \
+  }
+  if (len >= NB) {
+    if (!AP) pa += (NB - 1) * sa;
+    if (!BP) pb += (NB - 1) * sb;
+    const int16_t *pal = pa + (len - NB) * sa, *pbl = pb + (len - NB) * sb;
+#ifdef SF_SPLIT_PIPE
+    // software pipeline: the reads of batch n+1 are issued before batch n is reduced
+    int a2[NB], b2[NB];
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+      a[k] = pa[AP ? k * S : (NB - 1 - k) * (S - 1)];
+      b[k] = pb[BP ? k * S : (NB - 1 - k) * (S - 1)];
+    }
+    for (int nb = (len - 1) / NB; nb > 0; --nb) {
+      pa += NB * sa;
+      pb += NB * sb;
+      const int16_t *qa = nb > 1 ? pa : pal, *qb = nb > 1 ? pb : pbl;
+#pragma unroll
+      for (int k = 0; k < NB; k++) {
+        a2[k] = qa[AP ? k * S : (NB - 1 - k) * (S - 1)];
+        b2[k] = qb[BP ? k * S : (NB - 1 - k) * (S - 1)];
+      }
+      SF_SPLIT_REDUCE()
+#pragma unroll
+      for (int k = 0; k < NB; k++) { a[k] = a2[k]; b[k] = b2[k]; }
+    }
+    SF_SPLIT_REDUCE()
+#else
+    for (int nb = (len - 1) / NB; nb > 0; --nb) {
+#pragma unroll
+      for (int k = 0; k < NB; k++) {
+        a[k] = pa[AP ? k * S : (NB - 1 - k) * (S - 1)];
+        b[k] = pb[BP ? k * S : (NB - 1 - k) * (S - 1)];
+      }
+      SF_SPLIT_REDUCE()
+      pa += NB * sa;
+      pb += NB * sb;
+    }
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+      a[k] = pal[AP ? k * S : (NB - 1 - k) * (S - 1)];
+      b[k] = pbl[BP ? k * S : (NB - 1 - k) * (S - 1)];
+    }
+    SF_SPLIT_REDUCE()
+#endif
+  } else {
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+      const int t = k < NB - 1 ? sfd_min(k, len - 1) : len - 1;
+      a[k] = pa[t * sa];
+      b[k] = pb[t * sb];
+    }
+    SF_SPLIT_REDUCE()
+  }
+#undef SF_SPLIT_REDUCE
+}
+
 // One anti-diagonal for one thread.  H: this parity's per-size minima of the generic candidates of the
 // enclosed cell (i+1, j-1) on entry, of (i, j) on exit.  slot2 = (d-2) mod NR, slotd = d mod NR.
 // G ("guarded"): d < 36, the loop-size limit d-6 is below MAXLOOP and every size is tested against it;
@@ -209,7 +290,7 @@ struct SfFastCtx {
 //   SF_SEC_C0    hairpin and generic minima -> e0 (needs HP)
 //   SF_SEC_FIN   c = min(e0, eh, multiloop closing); publishes the cell (needs dec)
 enum { SF_SEC_P1 = 1, SF_SEC_HELP = 2, SF_SEC_DML = 4, SF_SEC_FIN = 8, SF_SEC_C0 = 16, SF_SEC_ALL = 31 };
-template <bool G, int WT, int SEC, bool CH = false>
+template <bool G, int WT, int SEC, bool CH = false, bool FOLD = false>
 __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, const int i, const bool valid,
                                              const int slot2, const int slotd, uint32_t (&HP)[14], int &ovf,
                                              const bool final_fml, const int fnb, int &fpart, int &dec, int &eh, int &e0,
@@ -234,8 +315,9 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
   const int um = CH ? d - 2 - (SFD_TURN + 1) : SFD_MAXLOOP;
   const int type = d <= X.maxd ? X.tPair[S[i] * 8 + S[j]] : 0;  // max_bp_span: longer pairs do not exist
   const int si1 = S[i + 1], sj1 = S[j - 1];
-// fML triangle without diagonals 0..3: base(d) = sum_{k=4}^{d-1} (W-k)
-#define FBASE(dd) (((dd)-4) * W - ((dd) * ((dd)-1) / 2 - 6))
+// first entry of diagonal dd.  Triangle without diagonals 0..3: sum_{k=4}^{dd-1} (W-k); FOLD: see the file header
+#define FBASE(dd) (FOLD ? ((dd) <= (W + 3) / 2 ? ((dd)-4) * (W - 3) : (W - 1 - (dd)) * (W - 3) + (dd)-3) \
+                        : (((dd)-4) * W - ((dd) * ((dd)-1) / 2 - 6)))
 // row of diagonal d-2-u in the rolling tables
 // (a v_readlane lane table for these offsets measured +1 % at W=120, -2 % at W=200, and is unsafe wherever the
 // build spills registers — see SF_UNI — so the scalar unit keeps computing them)
@@ -391,7 +473,32 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
   auto multiloop_split = [&]() {
     dec = SF_FAST_BIG;
 #ifndef SF_ABL_DML
-  {
+  if (FOLD) {
+    // min over m = 4 .. d-5 of fML[i, i+m] + fML[i+m+1, j] in the folded rectangle T (rows of S = W-3 entries):
+    //   fML[i, i+m]   = T[FBASE(m) + i0]            moves by +S per m while m <= H, by -(S-1) per m after that;
+    //   fML[i+m+1, j] = T[FBASE(d-1-m) + i0+m+1]    moves by +S per m while d-1-m > H, by -(S-1) per m after that
+    // (the lane's own shift by one per m cancels against the fold).  Inside a stretch of m in which neither operand
+    // changes sides every address of a batch of eight terms is the batch base plus a compile-time offset: one
+    // pointer bump per operand and batch instead of one per term (14 instead of 29 vector instructions per batch).
+    const int S_ = W - 3, H_ = (W + 3) / 2;
+    const int mend = d - SFD_TURN - 2;
+    const int bB = d - 1 - H_;  // first m whose second operand lies in the left part
+    int dec2 = SF_FAST_BIG;
+    const int16_t *T = X.fML + i0;
+    if (bB > SFD_TURN + 1) {  // stretch 1, m = 4 .. bB-1: both operands step by +S (second operand in the right part)
+      const int m0 = SFD_TURN + 1;
+      sf_fast_split_stretch<true, true>(T, T + (W - d + m0) * S_ + d - 3, bB - m0, S_, dec, dec2);
+    }
+    {  // stretch 2, m = max(4, bB) .. min(mend, H): first operand +S, second -(S-1) (both in the left part)
+      const int m0 = sfd_max(SFD_TURN + 1, bB), m1 = sfd_min(mend, H_);
+      if (m1 >= m0) sf_fast_split_stretch<true, false>(T + (m0 - 4) * S_, T + (d - 5 - m0) * S_ + m0 + 1, m1 - m0 + 1, S_, dec, dec2);
+    }
+    if (mend > H_) {  // stretch 3, m = H+1 .. mend: both operands step by -(S-1) (first operand in the right part)
+      const int m0 = H_ + 1;
+      sf_fast_split_stretch<false, false>(T + (W - 1 - m0) * S_ + m0 - 3, T + (d - 5 - m0) * S_ + m0 + 1, mend - H_, S_, dec, dec2);
+    }
+    dec = sfd_min(dec, dec2);
+  } else {
     // fML[i, i+m] = fML_tri[FBASE(m) + i0], fML[i+m+1, j] = fML_tri[FBASE(d-m-1) + i0+m+1].  Both offsets step by
     // wave-uniform differences, FBASE(m+1)-FBASE(m) = W-m: inside a batch of eight terms each address is the
     // previous one plus ONE uniform byte step (a single v_add with a scalar operand), the triangular part
@@ -551,12 +658,11 @@ __device__ __forceinline__ int sf_fast_c(const SfFastCtx &X, const int16_t *tExt
 __device__ inline int sf_fast_traceback(const SfFastCtx &X, const int32_t *f5s, const int16_t *tExt, const int lane,
                                         int16_t *stI, int16_t *stJ, int16_t *stM, char *dbL) {
   const int W = X.W;
+  const bool FOLD = X.fold != 0;
   const uint8_t *S = X.S;
   const SfDevParams *D = X.D;
 #define TC(i, j) sf_fast_c(X, tExt, (i), (j))
-// diagonals of odd length are followed by one pad entry when X.fml_pad is set
-#define SF_FPADCNT(dd) ((((dd) + (W & 1)) >> 1) - 2)
-#define TF(i, j) (((j) - (i) < SFD_TURN + 1) ? SF_INF16 : (int)X.fML[(FBASE((j) - (i)) + (X.fml_pad ? SF_FPADCNT((j) - (i)) : 0) + (i)-1) * X.fst])
+#define TF(i, j) (((j) - (i) < SFD_TURN + 1) ? SF_INF16 : (int)X.fML[FBASE((j) - (i)) + (i)-1])
 #define TPAIR(i, j) (((j) - (i)) <= X.maxd ? (int)X.tPair[S[i] * 8 + S[j]] : 0)
   for (int x = lane; x < W; x += 64) dbL[x] = '.';
   int sp = 0, bad = 0;
@@ -876,6 +982,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
                                                              int trace_stride, char *__restrict__ db_out,
                                                              int *__restrict__ status) {
   constexpr int NT = 2 * NG;
+  constexpr bool FOLD = (NG == 256);  // W > 128: fML in the folded rectangle (see the file header)
   const int W = WT ? WT : Wrt;
   SF_DYN_SMEM(smem);
   const SfFastLayout Lo = sf_fast_layout(W);
@@ -899,7 +1006,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
   int32_t *flag = (int32_t *)(smem + Lo.off_flag);
   uint8_t *S = (uint8_t *)(smem + Lo.off_S);
   X.S = S;
-  X.D = D; X.F = F; X.W = W; X.fml_pad = 0; X.fst = 1; X.maxd = D->max_pair_dist;
+  X.D = D; X.F = F; X.W = W; X.fold = FOLD; X.maxd = D->max_pair_dist;
   X.TAU = D->P.TerminalAU; X.MLbase = D->P.MLbase; X.MLclosing = D->P.MLclosing; X.MLintern = D->P.MLintern[1];
   // exterior pass aliases (the rolling CI area is dead by then)
   int32_t *f5s = (int32_t *)(smem + Lo.off_ci);
@@ -991,12 +1098,12 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
 #else
       if (__ballot(valid)) {
 #endif
-        if (d0 < SF_FAST_TINY_D0) sf_fast_cell<true, WT, SF_SEC_ALL>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev);
-        else if (d0 < SF_FAST_CHUNK_D0) sf_fast_cell<false, WT, SF_SEC_ALL, true>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev);
-        else if (!split) sf_fast_cell<false, WT, SF_SEC_ALL>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev);
-        else if (!helper) sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_DML>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev);
+        if (d0 < SF_FAST_TINY_D0) sf_fast_cell<true, WT, SF_SEC_ALL, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev);
+        else if (d0 < SF_FAST_CHUNK_D0) sf_fast_cell<false, WT, SF_SEC_ALL, true, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev);
+        else if (!split) sf_fast_cell<false, WT, SF_SEC_ALL, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev);
+        else if (!helper) sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_DML, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev);
         else {
-          sf_fast_cell<false, WT, SF_SEC_HELP>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev);
+          sf_fast_cell<false, WT, SF_SEC_HELP, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev);
           if (valid) X.BN[2 * (slotd * (W - 4) + i - 1) + 1] = (int16_t)sfd_min(eh, 32000);
         }
       }
@@ -1007,7 +1114,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
         __syncthreads();
         if (!helper && __ballot(valid)) {
           if (valid) eh = X.BN[2 * (slotd * (W - 4) + i - 1) + 1];
-          sf_fast_cell<false, WT, SF_SEC_FIN>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev);
+          sf_fast_cell<false, WT, SF_SEC_FIN, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev);
         }
       }
 #ifdef SF_STAMP

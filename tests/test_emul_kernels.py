@@ -32,27 +32,18 @@ def test_fast_and_full_mfe_kernels_match_oracle(emul, oracle):
         assert (emul.mfe_batch(arr) == ref).all(), W
         emul.set_kernel_mode(1)
         assert (emul.mfe_batch(arr) == ref).all(), W
-        emul.set_kernel_mode(2)  # packed two-cells-per-lane kernel (W <= 128; the emulation aborts on a misaligned pair read)
-        assert (emul.mfe_batch(arr) == ref).all(), W
-        emul.set_kernel_mode(3)  # two folds per workgroup, interleaved tables (W <= 128)
-        assert (emul.mfe_batch(arr) == ref).all(), W
-        assert (emul.mfe_batch(arr[: n - 1]) == ref[: n - 1]).all(), W  # odd count: the last pair is one fold twice
         emul.set_kernel_mode(0)
 
 
-@pytest.mark.parametrize("mode", [2, 3])
-def test_packed_kernels_odd_widths_and_traceback(emul, oracle, mode):
+def test_fast_kernel_odd_widths_and_traceback(emul, oracle):
+    """Widths around the layout seams of the LDS kernel (folded fML rectangle, wave-group boundaries)."""
     emul.load_params(params.default_params())
     rng = np.random.default_rng(11)
-    emul.set_kernel_mode(mode)
-    try:
-        for W in (16, 61, 99, 127, 128):
-            arr = random_seqs(rng, 3, W)
-            e, db = emul.mfe_trace_batch(arr)
-            for k in range(len(arr)):
-                assert (db[k], e[k]) == oracle.mfe(bytes(arr[k]).decode()), (W, k)
-    finally:
-        emul.set_kernel_mode(0)
+    for W in (16, 61, 67, 99, 121, 127, 128, 131):
+        arr = random_seqs(rng, 3, W)
+        e, db = emul.mfe_trace_batch(arr)
+        for k in range(len(arr)):
+            assert (db[k], e[k]) == oracle.mfe(bytes(arr[k]).decode()), (W, k)
 
 
 def test_int16_overflow_falls_back_to_exact_kernel(emul, oracle):
@@ -180,7 +171,7 @@ def test_max_bp_span_every_kernel(emul, oracle):
             emul.set_max_bp_span(span)
             ref = oracle.mfe_batch(arr)
             unlimited = None
-            for mode in (0, 1, 2, 3):
+            for mode in (0, 1):
                 emul.set_kernel_mode(mode)
                 assert (emul.mfe_batch(arr) == ref).all(), (W, span, mode)
             emul.set_kernel_mode(0)

@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; rm -rf $R/gpurun_out/pkpmc
 for c in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_WAIT_INST_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_ACTIVE_INST_LDS" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU"; do
   d=$R/gpurun_out/pkpmc/$(echo $c | tr " " "_" | cut -c1-40)
-  timeout 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $d -- python3 $R/tools/gpu_mfe_modes.py 131072 120 ${SF_MODE:-0} > /dev/null 2>&1
+  timeout 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $d -- python3 $R/tools/gpu_mfe_only.py 131072 120 > /dev/null 2>&1
 done
 python3 - <<PY
 import csv, glob

@@ -38,7 +38,8 @@ typedef enum sf_status {
   SF_ERR_TEMPERATURE = -5,  /* requested temperature differs from the one the blob is valid at */
   SF_ERR_HIP = -6,          /* a HIP runtime call failed; sf_last_hip_error() has the text */
   SF_ERR_NO_DEVICE = -7,    /* no usable GPU */
-  SF_ERR_INTERNAL = -8      /* a traceback found no decomposition (would indicate a kernel bug) */
+  SF_ERR_INTERNAL = -8,     /* a traceback found no decomposition (would indicate a kernel bug) */
+  SF_ERR_CONSTRAINT = -9    /* unbalanced brackets in a window's constraint string (ViennaRNA aborts there) */
 } sf_status;
 
 #define SF_MAX_W 400 /* longest window the kernels accept */
@@ -72,6 +73,23 @@ int sf_mfe_trace_batch(const uint8_t *seqs, int n, int W, int32_t *mfe_dcal_out,
  * 395,400-401).  Any output pointer may be NULL.  ensemble_dG in kcal/mol; centroid_out n rows of W+1. */
 int sf_pf_batch(const uint8_t *seqs, int n, int W, double *ensemble_dG, double *mean_bp_dist, char *centroid_out,
                 double *centroid_dist);
+
+/* fc.hc_add_from_db(window_constraints) and fc.sc_add_SHAPE_deigan(window_reactivities, m, b) followed by fc.mfe(),
+ * fc.pf(), fc.centroid(), fc.mean_bp_distance() (ScanFold-Scan.py:405-418; ScanFold.py:508-544) for n windows of W nt.
+ *   cons           n rows of W characters, or NULL: '.', 'x', '|', '<', '>', '(' and ')' with ViennaRNA's non-enforcing
+ *                  default semantics ('x' unpaired; '<' / '>' may pair downstream / upstream only; a bracket pair may
+ *                  pair with each other only — type 7 if not complementary — and nothing may cross it; '|' and '.'
+ *                  change nothing).  Unbalanced brackets in a row: SF_ERR_CONSTRAINT.
+ *   sc_stack_dcal  n rows of W int32 (dcal/mol), or NULL: the Deigan pseudo-energy of each nucleotide, added to every
+ *                  stacked pair it takes part in — MFE and traceback only, as the reference adds SHAPE data after its
+ *                  partition function call.
+ * Outputs as sf_mfe_trace_batch / sf_pf_batch; any may be NULL.  flags: SF_FOLD_NO_PF, SF_FOLD_NO_MFE.
+ * These folds run on the general int32 / FP64 kernels; shuffles are folded unconstrained, as upstream. */
+#define SF_FOLD_NO_PF 1u
+#define SF_FOLD_NO_MFE 2u
+int sf_fold_constrained(const uint8_t *seqs, int n, int W, const char *cons, const int32_t *sc_stack_dcal,
+                        unsigned flags, int32_t *mfe_dcal_out, char *db_out, double *ensemble_dG, double *mean_bp_dist,
+                        char *centroid_out, double *centroid_dist);
 
 /* scramble(text, r, type) (ScanFold-Scan.py:266-282; ScanFoldFunctions.py:834-851) for n_win windows at
  * once: window w is transcript[(win_begin+w)*step .. +W).  Output: n_win*(r+1) rows of W codes (0..4); row 0
@@ -107,7 +125,7 @@ int sf_last_status(void);
 /* Maximum base-pair span of the folding model.  Replaces md.max_bp_span = args.span (ScanFold.py:214-215; the
  * Scan stage script has no such flag): base pairs (i, j) with j - i + 1 > span do not exist, in the MFE fill, the
  * partition function and the traceback.  span <= 0 removes the limit (the default).  Survives sf_params_load.
- * SURVEY.md 8(f) rank 1, first item; hard constraints and temperatures != 37 C are not implemented. */
+ * SURVEY.md 8(f) rank 1, first item. */
 int sf_set_max_bp_span(int span);
 
 /* Diagnostics: 0 = automatic (LDS int16 kernel with int32 fallback), 1 = always the int32 kernel.

@@ -36,6 +36,7 @@ def lib():
                              ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
         L.sfo_scan_windows.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        L.sfo_set_constraint.argtypes = [ctypes.c_char_p, ctypes.c_void_p]
         L.sfo_shuffle_windows.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                           ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.c_void_p]
         _lib = L
@@ -53,6 +54,18 @@ def set_params(paramset):
 def set_max_bp_span(span):
     """RNA.md().max_bp_span: pairs (i, j) with j - i + 1 > span do not exist; <= 0 removes the limit."""
     lib().sfo_set_max_bp_span(int(span or 0))
+
+
+_keep = []
+
+
+def set_constraint(cons=None, sc_stack_dcal=None):
+    """fc.hc_add_from_db(cons) / fc.sc_add_SHAPE_deigan pseudo-energies (int dcal per nucleotide, stacks only) for the
+    following single-sequence calls (mfe, eval_structure, brute, pf); None, None clears.  See sf_oracle.c."""
+    c = cons.encode() if isinstance(cons, str) else cons
+    s = None if sc_stack_dcal is None else np.ascontiguousarray(sc_stack_dcal, dtype=np.int32)
+    _keep[:] = [c, s]  # the C side keeps the pointers
+    lib().sfo_set_constraint(c, None if s is None else s.ctypes.data)
 
 
 def mfe(seq, structure=True):

@@ -169,7 +169,34 @@ typedef struct {
   int n;
   int *S;    /* 0..n+1 */
   char *str; /* normalised, NUL terminated */
+  /* hard constraint of this sequence (NULL: none): the dot-bracket string, bracket partners (0: none) and, per
+   * position, the innermost bracket pair that encloses it (index of its opening position, 0: none) */
+  const char *cons;
+  int *partner, *encl;
+  const int *sc_stack; /* soft constraint: pseudo-energy (dcal/mol) of position i when it sits in a stacked pair; 0-based, NULL: none */
+  int cons_bad;        /* unbalanced brackets */
 } seq_t;
+
+/* fc.hc_add_from_db(window_constraints) (ScanFold-Scan.py:405-410; ScanFold.py:508-512) and
+ * fc.sc_add_SHAPE_deigan(...) (ScanFold.py:533-539) for the NEXT single-sequence calls (sfo_mfe, sfo_eval, sfo_brute,
+ * sfo_pf); the batch entry points ignore it.  Semantics restated from ViennaRNA 2.4's vrna_hc_add_from_db with its
+ * default options — no VRNA_CONSTRAINT_DB_ENFORCE_BP — [EXT, unverifiable here]:
+ *   '.'  no constraint          'x'  the position stays unpaired
+ *   '|'  no effect (without the enforce option a position is merely ALLOWED to pair in either direction)
+ *   '<'  the position may only pair with a position downstream (it cannot be the 3' partner of a pair)
+ *   '>'  the position may only pair with a position upstream (it cannot be the 5' partner)
+ *   '(' ')'  the two positions may pair with each other only (also if the bases are not complementary: pair
+ *        type 7), and no pair may cross theirs; they are not forced to pair
+ * Unbalanced brackets are an error (ViennaRNA aborts the process there).  The Deigan term of position i is added to
+ * every stack (interior loop without unpaired bases) i takes part in, in the MFE model only: the reference adds SHAPE
+ * data after its partition function call (ScanFold.py:525-539). */
+static const char *g_cons = NULL;
+static const int *g_sc_stack = NULL;
+int sfo_set_constraint(const char *cons, const int *sc_stack_dcal) {
+  g_cons = cons;
+  g_sc_stack = sc_stack_dcal;
+  return 0;
+}
 
 static void seq_init(seq_t *q, const char *seq, int n) {
   q->n = n;
@@ -177,17 +204,52 @@ static void seq_init(seq_t *q, const char *seq, int n) {
   q->str = (char *)malloc((size_t)n + 1);
   for (int i = 0; i < n; i++) q->S[i + 1] = encode_char(seq[i], &q->str[i]);
   q->str[n] = 0;
+  q->cons = g_cons;
+  q->sc_stack = g_sc_stack;
+  q->partner = q->encl = NULL;
+  q->cons_bad = 0;
+  if (q->cons) {
+    q->partner = (int *)calloc((size_t)n + 2, sizeof(int));
+    q->encl = (int *)calloc((size_t)n + 2, sizeof(int));
+    int *stack = (int *)malloc(sizeof(int) * (size_t)(n + 1)), sp = 0;
+    for (int i = 1; i <= n; i++) {
+      const char ch = q->cons[i - 1];
+      if (ch == ')') {
+        if (sp == 0) { q->cons_bad = 1; break; }
+        const int o = stack[--sp];
+        q->partner[o] = i;
+        q->partner[i] = o;
+      }
+      q->encl[i] = sp ? stack[sp - 1] : 0; /* a bracket position itself: the pair around its own pair */
+      if (ch == '(') stack[sp++] = i;
+    }
+    if (sp) q->cons_bad = 1;
+    free(stack);
+  }
 }
 static void seq_free(seq_t *q) {
   free(q->S);
   free(q->str);
+  free(q->partner);
+  free(q->encl);
 }
 /* RNA.md().max_bp_span (ScanFold.py:214-215; [EXT] ViennaRNA: a pair (i,j) needs j - i + 1 <= max_bp_span); <= 0: none */
 static int g_max_bp_span = 0;
 int sfo_set_max_bp_span(int span) { g_max_bp_span = span > 0 ? span : 0; return 0; }
 static inline int ptype(const seq_t *q, int i, int j) {
   if (g_max_bp_span > 0 && j - i + 1 > g_max_bp_span) return 0;
-  return pair_tab[q->S[i]][q->S[j]];
+  const int t = pair_tab[q->S[i]][q->S[j]];
+  if (!q->cons) return t;
+  if (q->partner[i] || q->partner[j]) return q->partner[i] == j ? (t ? t : 7) : 0;
+  const char ci = q->cons[i - 1], cj = q->cons[j - 1];
+  if (ci == 'x' || cj == 'x' || ci == '>' || cj == '<') return 0;
+  if (q->encl[i] != q->encl[j]) return 0; /* would cross a bracket pair */
+  return t;
+}
+/* Deigan pseudo-energy of the stack (i,j) on (i+1,j-1) */
+static inline int sc_stack_term(const seq_t *q, int i, int j, int p, int qq) {
+  if (!q->sc_stack || p != i + 1 || qq != j - 1) return 0;
+  return q->sc_stack[i - 1] + q->sc_stack[p - 1] + q->sc_stack[qq - 1] + q->sc_stack[j - 1];
 }
 
 /* ---------- loop energies ---------- */
@@ -381,6 +443,7 @@ static void mfe_fill(const seq_t *q, mfe_tabs *t) {
             int t2 = ptype(q, p, qq);
             if (!t2) continue;
             int en = E_intloop(p - i - 1, j - qq - 1, type, rtype[t2], S[i + 1], S[j - 1], S[p - 1], S[qq + 1]) +
+                     sc_stack_term(q, i, j, p, qq) +
                      c[IX(p, qq)];
             e = MIN2(e, en);
           }
@@ -495,6 +558,7 @@ static int mfe_traceback(const seq_t *q, const mfe_tabs *t, char *db) {
           int t2 = ptype(q, p, qq);
           if (!t2) continue;
           int en = E_intloop(p - i - 1, j - qq - 1, type, rtype[t2], S[i + 1], S[j - 1], S[p - 1], S[qq + 1]) +
+                   sc_stack_term(q, i, j, p, qq) +
                    c[IX(p, qq)];
           if (cij == en) { found = 1; break; }
         }
@@ -524,6 +588,7 @@ int sfo_mfe(const char *seq, int n, int *mfe_dcal, char *structure) {
   seq_t q;
   mfe_tabs t;
   seq_init(&q, seq, n);
+  if (q.cons_bad) { seq_free(&q); return -3; }
   mfe_fill(&q, &t);
   if (mfe_dcal) *mfe_dcal = t.f5[n];
   int rc = 0;
@@ -540,8 +605,11 @@ int sfo_mfe_batch(const char *seqs, int nseq, int W, int *out, int nthreads) {
   if (nthreads > 0) omp_set_num_threads(nthreads);
 #endif
   (void)nthreads;
+  const char *keep_c = g_cons; const int *keep_s = g_sc_stack;
+  g_cons = NULL; g_sc_stack = NULL;
 #pragma omp parallel for schedule(dynamic, 4)
   for (int k = 0; k < nseq; k++) sfo_mfe(seqs + (size_t)k * W, W, &out[k], NULL);
+  g_cons = keep_c; g_sc_stack = keep_s;
   return 0;
 }
 
@@ -559,6 +627,7 @@ int sfo_scan_windows(const char *rows, int n_win, int r, int W, int *energies, c
 #endif
   (void)nthreads;
   int bad = 0;
+  g_cons = NULL; g_sc_stack = NULL; /* batch entry points are unconstrained */
 #pragma omp parallel for schedule(dynamic, 1)
   for (int w = 0; w < n_win; w++) {
     const char *base = rows + (size_t)w * (r + 1) * W;
@@ -609,7 +678,8 @@ static int eval_loop(const seq_t *q, const int *pt, int i, int j, int *bad) {
   }
   if (nstems == 0) return E_hairpin(j - i - 1, type, S[i + 1], S[j - 1], q->str + i - 1);
   if (nstems == 1)
-    return E_intloop(p1 - i - 1, j - q1 - 1, type, rtype[ptype(q, p1, q1)], S[i + 1], S[j - 1], S[p1 - 1], S[q1 + 1]);
+    return E_intloop(p1 - i - 1, j - q1 - 1, type, rtype[ptype(q, p1, q1)], S[i + 1], S[j - 1], S[p1 - 1], S[q1 + 1]) +
+           sc_stack_term(q, i, j, p1, q1);
   return P.MLclosing + E_mlstem(rtype[type], S[j - 1], S[i + 1]) + e_stems + unp * P.MLbase;
 }
 
@@ -633,6 +703,7 @@ int sfo_eval(const char *seq, const char *structure, int n, int *energy) {
   if (!have_params) return -10;
   seq_t q;
   seq_init(&q, seq, n);
+  if (q.cons_bad) { seq_free(&q); return -3; }
   int *pt = (int *)malloc(sizeof(int) * (size_t)(n + 2));
   int rc = make_pair_table(structure, n, pt), bad = 0;
   if (rc == 0) {
@@ -757,6 +828,7 @@ int sfo_brute(const char *seq, int n, int *mfe_dcal, double *Z, double *bpp, lon
   if (n > 26) return -3;
   seq_t q;
   seq_init(&q, seq, n);
+  if (q.cons_bad) { seq_free(&q); return -3; }
   brute_ctx b;
   b.q = &q;
   b.pt = (int *)calloc((size_t)n + 2, sizeof(int));
@@ -787,6 +859,7 @@ int sfo_pf(const char *seq, int n, double *ensemble_dG, double *bpp_out, char *c
   if (!have_params) return -10;
   seq_t q;
   seq_init(&q, seq, n);
+  if (q.cons_bad) { seq_free(&q); return -3; }
   const int *S = q.S;
   size_t sz = (size_t)(n + 2) * (size_t)(n + 2);
   double *qb = (double *)calloc(sz, sizeof(double));

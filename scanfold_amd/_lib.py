@@ -32,6 +32,9 @@ _EXPORTS = {
     "sf_mfe_trace_batch": (ctypes.c_int, [_c_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "sf_pf_batch": (ctypes.c_int, [_c_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                    ctypes.c_void_p, ctypes.c_void_p]),
+    "sf_fold_constrained": (ctypes.c_int, [_c_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                           ctypes.c_uint, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "sf_shuffle_windows": (ctypes.c_int, [_c_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                           ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint64,
                                           ctypes.c_void_p]),
@@ -133,10 +136,29 @@ class Engine:
         return buf.value.decode()
 
     def load_params(self, paramset, temperature=None):
+        """RNA.md() + RNA.fold_compound(seq, md): make `paramset` the folding model.  `temperature` other than the
+        set's own rescales it first (ParamSet.at_temperature: needs the enthalpy tables of a real .par file)."""
+        if temperature is not None and float(temperature) != paramset.temperature:
+            paramset = paramset.at_temperature(temperature)
         blob = paramset.blob()
-        t = paramset.temperature if temperature is None else float(temperature)
-        self._check(self.lib.sf_params_load(blob, len(blob), t))
+        self._check(self.lib.sf_params_load(blob, len(blob), paramset.temperature))
         self.params = paramset
+        self._by_temp = {paramset.temperature: paramset}
+
+    def set_temperature(self, temperature):
+        """md.temperature = T (ScanFold-Scan.py:70-71; ScanFoldFunctions.py:776-777): switch the resident model to the
+        loaded set rescaled to T; a no-op when it is already there.  Raises NotImplementedError for a set without
+        enthalpies (the reconstructed default) when T is not the set's temperature."""
+        t = float(temperature)
+        if t == self.params.temperature:
+            return
+        cache = self._by_temp
+        if t not in cache:
+            cache[t] = self.params.at_temperature(t)
+        p = cache[t]
+        blob = p.blob()
+        self._check(self.lib.sf_params_load(blob, len(blob), p.temperature))
+        self.params = p
 
     def shutdown(self):
         self._check(self.lib.sf_shutdown())
@@ -167,6 +189,32 @@ class Engine:
         self._check(self.lib.sf_pf_batch(arr.ctypes.data, n, W, dG.ctypes.data, mbd.ctypes.data, cen.ctypes.data,
                                          cd.ctypes.data))
         return dict(dG=dG, mean_bp_dist=mbd, centroid=[bytes(r[:W]).decode() for r in cen], centroid_dist=cd)
+
+    def fold_constrained(self, seqs, cons=None, sc_stack_dcal=None, mfe=True, pf=True):
+        """fc.hc_add_from_db / fc.sc_add_SHAPE_deigan + fc.mfe() / fc.pf() on n windows (ScanFold-Scan.py:405-418;
+        ScanFold.py:508-544).  cons: list of W-char str or uint8 (n, W); sc_stack_dcal: int32 (n, W).
+        -> dict(mfe, structure [str], dG, mean_bp_dist, centroid [str], centroid_dist) (the keys that were asked for)"""
+        arr = seqs_to_array(seqs)
+        n, W = arr.shape
+        c = None if cons is None else seqs_to_array(cons)
+        if c is not None and c.shape != (n, W):
+            raise ValueError("constraint rows must match the sequence rows")
+        s = None if sc_stack_dcal is None else np.ascontiguousarray(sc_stack_dcal, dtype=np.int32).reshape(n, W)
+        e = np.zeros(n, dtype=np.int32)
+        db = np.zeros((n, W + 1), dtype=np.uint8)
+        dG, mbd, cd = np.zeros(n), np.zeros(n), np.zeros(n)
+        cen = np.zeros((n, W + 1), dtype=np.uint8)
+        flags = (0 if pf else 1) | (0 if mfe else 2)
+        self._check(self.lib.sf_fold_constrained(arr.ctypes.data, n, W, None if c is None else c.ctypes.data,
+                                                 None if s is None else s.ctypes.data, flags, e.ctypes.data,
+                                                 db.ctypes.data, dG.ctypes.data, mbd.ctypes.data, cen.ctypes.data,
+                                                 cd.ctypes.data))
+        out = {}
+        if mfe:
+            out.update(mfe=e, structure=[bytes(r[:W]).decode() for r in db])
+        if pf:
+            out.update(dG=dG, mean_bp_dist=mbd, centroid=[bytes(r[:W]).decode() for r in cen], centroid_dist=cd)
+        return out
 
     def shuffle_windows(self, transcript, W, step, win_begin, n_win, r, kind, seed):
         tr = np.frombuffer(transcript.encode("ascii") if isinstance(transcript, str) else bytes(transcript),

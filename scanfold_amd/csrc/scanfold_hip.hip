@@ -39,7 +39,7 @@ struct Ctx {
   SfDevParamsPF *dX = nullptr;
   SfFastParams *dF = nullptr;
   double temperature = 37.0;
-  DevBuf full_scratch, pf_scratch, pf_share, fast_scratch, seqs, energies, db, cen, dbl, status, transcript, ovf;
+  DevBuf full_scratch, pf_scratch, pf_share, fast_scratch, seqs, energies, db, cen, dbl, status, transcript, ovf, cons, sc;
   std::string last_hip_error;
   // profiling of the dominant kernel
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;  // recorded only while profiling is on (sf_prof_reset)
@@ -179,13 +179,14 @@ int max_resident_blocks() { return g.n_cu * 4; }
 
 // FULL kernel over n items; see sf_mfe_full_kernel for the indexing arguments
 int launch_full(const uint8_t *d_seqs, const int *d_idx, const int *d_count, int n, int row_stride, int mfe_stride,
-                int W, int32_t *d_mfe, char *d_db, int db_stride, hipStream_t st) {
+                int W, int32_t *d_mfe, char *d_db, int db_stride, hipStream_t st, const char *d_cons = nullptr,
+                const int32_t *d_sc = nullptr) {
   if (n <= 0) return SF_OK;
   int grid = n < max_resident_blocks() ? n : max_resident_blocks();
   int rc = ensure(g.full_scratch, (size_t)grid * SF_FULL_SCRATCH_INTS(W) * sizeof(int32_t));
   if (rc) return rc;
   SF_LAUNCH(sf_mfe_full_kernel, grid, block_threads(W), 0, st, d_seqs, d_idx, d_count, n, row_stride, mfe_stride, W,
-            (const SfDevParams *)g.dP, (int32_t *)g.full_scratch.p, d_mfe, d_db, db_stride, (int *)g.status.p);
+            (const SfDevParams *)g.dP, (int32_t *)g.full_scratch.p, d_mfe, d_db, db_stride, (int *)g.status.p, d_cons, d_sc);
   HIPCHK(hipGetLastError());
   return SF_OK;
 }
@@ -232,7 +233,8 @@ int launch_pf(const uint8_t *d_seqs, int n, int row_stride, int W, double *d_dG,
     int rc = ensure(g.pf_scratch, (size_t)grid * SF_PF_SCRATCH_DOUBLES(W) * sizeof(double));
     if (rc) return rc;
     SF_LAUNCH(sf_pf_kernel, grid, block_threads(W), 0, st, d_seqs, n, row_stride, W, (const SfDevParams *)g.dP,
-              (const SfDevParamsPF *)g.dX, (double *)g.pf_scratch.p, d_dG, d_mbd, d_cen, d_cd);
+              (const SfDevParamsPF *)g.dX, (double *)g.pf_scratch.p, d_dG, d_mbd, d_cen, d_cd, (const char *)nullptr,
+              (int *)nullptr);
   }
   HIPCHK(hipGetLastError());
   return SF_OK;
@@ -334,6 +336,7 @@ int read_status(hipStream_t st, bool whole_device) {
   else HIPCHK(hipStreamSynchronize(st));
   HIPCHK(hipMemcpy(&v, g.status.p, sizeof(int), hipMemcpyDeviceToHost));
   if (v) HIPCHK(hipMemset(g.status.p, 0, sizeof(int)));
+  if (v & 2) return SF_ERR_CONSTRAINT;  // unbalanced brackets in a window's constraint string
   return v ? SF_ERR_INTERNAL : SF_OK;
 }
 
@@ -352,6 +355,7 @@ const char *sf_strerror(int status) {
     case SF_ERR_HIP: return "HIP runtime error (see sf_last_hip_error)";
     case SF_ERR_NO_DEVICE: return "no usable GPU device";
     case SF_ERR_INTERNAL: return "internal error: traceback found no decomposition";
+    case SF_ERR_CONSTRAINT: return "unbalanced brackets in a window's constraint string";
     default: return "unknown status";
   }
 }
@@ -399,7 +403,7 @@ int sf_shutdown(void) {
   if (!g.init) return SF_OK;
   hipDeviceSynchronize();
   DevBuf *bufs[] = {&g.full_scratch, &g.pf_scratch, &g.pf_share, &g.fast_scratch, &g.seqs, &g.energies, &g.db, &g.cen,
-                    &g.dbl, &g.status, &g.transcript, &g.ovf};
+                    &g.dbl, &g.status, &g.transcript, &g.ovf, &g.cons, &g.sc};
   for (DevBuf *b : bufs) {
     if (b->p) hipFree(b->p);
     b->p = nullptr;
@@ -503,6 +507,59 @@ int sf_pf_batch(const uint8_t *seqs, int n, int W, double *ens_dG, double *mbd, 
   if (centroid) HIPCHK(hipMemcpyAsync(centroid, g.cen.p, (size_t)n * (W + 1), hipMemcpyDeviceToHost, g.stream));
   HIPCHK(hipStreamSynchronize(g.stream));
   return SF_OK;
+}
+
+// fc.hc_add_from_db(window_constraints) / fc.sc_add_SHAPE_deigan(...) followed by fc.mfe(), fc.pf(), fc.centroid(),
+// fc.mean_bp_distance() on n windows (ScanFold-Scan.py:405-418; ScanFold.py:508-544): the general int32 / FP64 kernels
+// with the window's constraint applied where they compute a pair type.  Only native windows come here — the
+// reference folds its shuffles unconstrained — so the LDS kernels of the hot path are not involved.
+int sf_fold_constrained(const uint8_t *seqs, int n, int W, const char *cons, const int32_t *sc_stack_dcal, unsigned flags,
+                        int32_t *mfe_out, char *db_out, double *ens_dG, double *mbd, char *centroid, double *cdist) {
+  int rc = check_ready();
+  if (rc) return rc;
+  if (n < 0 || W < 1 || W > SF_MAX_W || (n > 0 && !seqs)) return SF_ERR_BAD_ARG;
+  if (n == 0) return SF_OK;
+  const bool want_mfe = !(flags & SF_FOLD_NO_MFE), want_pf = !(flags & SF_FOLD_NO_PF);
+  if ((rc = ensure(g.seqs, (size_t)n * W))) return rc;
+  HIPCHK(hipMemcpyAsync(g.seqs.p, seqs, (size_t)n * W, hipMemcpyHostToDevice, g.stream));
+  const char *d_cons = nullptr;
+  const int32_t *d_sc = nullptr;
+  if (cons) {
+    if ((rc = ensure(g.cons, (size_t)n * W))) return rc;
+    HIPCHK(hipMemcpyAsync(g.cons.p, cons, (size_t)n * W, hipMemcpyHostToDevice, g.stream));
+    d_cons = (const char *)g.cons.p;
+  }
+  if (sc_stack_dcal) {
+    if ((rc = ensure(g.sc, (size_t)n * W * sizeof(int32_t)))) return rc;
+    HIPCHK(hipMemcpyAsync(g.sc.p, sc_stack_dcal, (size_t)n * W * sizeof(int32_t), hipMemcpyHostToDevice, g.stream));
+    d_sc = (const int32_t *)g.sc.p;
+  }
+  if (want_mfe) {
+    if ((rc = ensure(g.energies, (size_t)n * sizeof(int32_t)))) return rc;
+    if ((rc = ensure(g.db, (size_t)n * (W + 1)))) return rc;
+    if ((rc = launch_full((const uint8_t *)g.seqs.p, nullptr, nullptr, n, 1, 1, W, (int32_t *)g.energies.p,
+                          db_out ? (char *)g.db.p : nullptr, 0, g.stream, d_cons, d_sc)))
+      return rc;
+    if (mfe_out)
+      HIPCHK(hipMemcpyAsync(mfe_out, g.energies.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, g.stream));
+    if (db_out) HIPCHK(hipMemcpyAsync(db_out, g.db.p, (size_t)n * (W + 1), hipMemcpyDeviceToHost, g.stream));
+  }
+  if (want_pf) {
+    int grid = n < max_resident_blocks() ? n : max_resident_blocks();
+    if ((rc = ensure(g.dbl, (size_t)n * 3 * sizeof(double)))) return rc;
+    if ((rc = ensure(g.cen, (size_t)n * (W + 1)))) return rc;
+    if ((rc = ensure(g.pf_scratch, (size_t)grid * SF_PF_SCRATCH_DOUBLES(W) * sizeof(double)))) return rc;
+    double *d_dG = (double *)g.dbl.p, *d_mbd = d_dG + n, *d_cd = d_mbd + n;
+    SF_LAUNCH(sf_pf_kernel, grid, block_threads(W), 0, g.stream, (const uint8_t *)g.seqs.p, n, 1, W,
+              (const SfDevParams *)g.dP, (const SfDevParamsPF *)g.dX, (double *)g.pf_scratch.p, d_dG, d_mbd,
+              (char *)g.cen.p, d_cd, d_cons, (int *)g.status.p);
+    HIPCHK(hipGetLastError());
+    if (ens_dG) HIPCHK(hipMemcpyAsync(ens_dG, d_dG, n * sizeof(double), hipMemcpyDeviceToHost, g.stream));
+    if (mbd) HIPCHK(hipMemcpyAsync(mbd, d_mbd, n * sizeof(double), hipMemcpyDeviceToHost, g.stream));
+    if (cdist) HIPCHK(hipMemcpyAsync(cdist, d_cd, n * sizeof(double), hipMemcpyDeviceToHost, g.stream));
+    if (centroid) HIPCHK(hipMemcpyAsync(centroid, g.cen.p, (size_t)n * (W + 1), hipMemcpyDeviceToHost, g.stream));
+  }
+  return read_status(g.stream, false);
 }
 
 static int check_scan_args(int L, int W, int step, int win_begin, int n_win, int r, int kind) {

@@ -9,7 +9,8 @@
 #define SFD_TURN SF_TURN
 #define SFD_MAXLOOP SF_MAXLOOP
 
-__device__ __forceinline__ int sfd_rtype(int t) { return t ? (((t - 1) ^ 1) + 1) : 0; }
+// reverse pair type: CG <-> GC, GU <-> UG, AU <-> UA; 0 and the non-standard type 7 (a pair forced by a constraint) map to themselves
+__device__ __forceinline__ int sfd_rtype(int t) { return (t && t < 7) ? (((t - 1) ^ 1) + 1) : t; }
 __device__ __forceinline__ int sfd_min(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int sfd_max(int a, int b) { return a > b ? a : b; }
 
@@ -147,6 +148,46 @@ __device__ inline double sfx_extloop(const SfDevParamsPF *X, int type, int si1, 
   else if (sj1 >= 0) z = X->dangle3[type][sj1];
   if (type > 2) z *= X->TermAU;
   return z;
+}
+
+// ---------------- hard constraints of one window (fc.hc_add_from_db, ScanFold-Scan.py:405-410) ----------------
+// ViennaRNA 2.4's vrna_hc_add_from_db with its default options (no enforce) [EXT]: 'x' stays unpaired; '<' / '>' may only
+// pair downstream / upstream; '(' ')' may pair with each other only (type 7 if the bases are not complementary) and
+// nothing may cross them; '|' and '.' change nothing.  Parsed once per window by one thread into LDS.
+struct SfHc {
+  const char *c;           // the window's constraint characters, 1-based (c[1..W]); null: no constraint
+  const int16_t *partner;  // bracket partner of a position, 0: none
+  const int16_t *encl;     // opening position of the innermost bracket pair around a position, 0: none
+};
+// returns 0 if the brackets balance.  c / partner / encl / stack: LDS arrays of W + 2 entries, filled for 1..W
+__device__ inline int sf_hc_parse(const char *src, int W, char *c, int16_t *partner, int16_t *encl, int16_t *stack) {
+  int sp = 0, bad = 0;
+  for (int i = 1; i <= W; i++) {
+    const char ch = src[i - 1];
+    c[i] = ch;
+    partner[i] = 0;
+  }
+  for (int i = 1; i <= W && !bad; i++) {
+    const char ch = c[i];
+    if (ch == ')') {
+      if (sp == 0) { bad = 1; break; }
+      const int o = stack[--sp];
+      partner[o] = (int16_t)i;
+      partner[i] = (int16_t)o;
+    }
+    encl[i] = sp ? stack[sp - 1] : 0;
+    if (ch == '(') stack[sp++] = (int16_t)i;
+  }
+  return bad || sp != 0;
+}
+// pair type of (i, j), i < j, under the constraint; t = the unconstrained type (0 where the span limit forbids the pair)
+__device__ __forceinline__ int sf_hc_type(const SfHc &h, int t, int i, int j, bool span_ok) {
+  if (!h.c) return t;
+  if (h.partner[i] || h.partner[j]) return (h.partner[i] == j && span_ok) ? (t ? t : 7) : 0;
+  const char ci = h.c[i], cj = h.c[j];
+  if (ci == 'x' || cj == 'x' || ci == '>' || cj == '<') return 0;
+  if (h.encl[i] != h.encl[j]) return 0;  // would cross a bracket pair
+  return t;
 }
 
 // ASCII or code -> code 0..4 (N,A,C,G,U)

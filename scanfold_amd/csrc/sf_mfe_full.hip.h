@@ -33,7 +33,15 @@ __global__ void sf_mfe_full_kernel(const uint8_t *__restrict__ seqs, const int *
                                    const int *__restrict__ count_ptr, int n, int row_stride, int mfe_stride, int W,
                                    const SfDevParams *__restrict__ D, int32_t *__restrict__ scratch,
                                    int32_t *__restrict__ mfe_out, char *__restrict__ db_out, int db_stride,
-                                   int *__restrict__ status) {
+                                   int *__restrict__ status, const char *__restrict__ cons_rows,
+                                   const int32_t *__restrict__ sc_rows) {
+  // cons_rows: item k's hard constraint = W characters at cons_rows + k*W (fc.hc_add_from_db, ScanFold-Scan.py:405-410);
+  // sc_rows: item k's Deigan pseudo-energies (dcal/mol per nucleotide, added to every stack the nucleotide is part of:
+  // fc.sc_add_SHAPE_deigan, ScanFold.py:533-539) at sc_rows + k*W.  Null = none (the plain RNA.fold of the hot path).
+  __shared__ char hcC[SF_MAX_W + 2];
+  __shared__ int16_t hcP[SF_MAX_W + 2], hcE[SF_MAX_W + 2], hcStk[SF_MAX_W + 2];
+  __shared__ int scS[SF_MAX_W + 2];
+  __shared__ int hcBad;
   __shared__ uint8_t S[SF_MAX_W + 2];
   __shared__ int f5s[SF_MAX_W + 1];
   __shared__ int red[8];
@@ -55,12 +63,32 @@ __global__ void sf_mfe_full_kernel(const uint8_t *__restrict__ seqs, const int *
     for (int x = tid; x < W; x += nthreads) S[x + 1] = sf_encode_nt(src[x]);
     if (tid == 0) { S[0] = 0; S[W + 1] = 0; f5s[0] = 0; }
     for (int x = tid; x < 4 * W1 && x < W * W1; x += nthreads) { c[x] = SFD_INF; fML[x] = SFD_INF; DML[x] = SFD_INF; }
+    SfHc hc;
+    hc.c = cons_rows ? hcC : nullptr; hc.partner = hcP; hc.encl = hcE;
+    if (cons_rows && tid == 0) hcBad = sf_hc_parse(cons_rows + (size_t)k * W, W, hcC, hcP, hcE, hcStk);
+    if (sc_rows)
+      for (int x = tid; x < W; x += nthreads) scS[x + 1] = sc_rows[(size_t)k * W + x];
     __syncthreads();
+    if (cons_rows && hcBad) {  // unbalanced brackets: report, fold nothing (ViennaRNA aborts the process here)
+      if (tid == 0) {
+        if (status) atomicOr(status, 2);
+        if (mfe_out) mfe_out[idx_list ? idx_list[k] : k * mfe_stride] = 0;
+      }
+      continue;
+    }
+    // pair type under the window's constraint; stack term of the soft constraint
+    auto PTY = [&](int a, int b) -> int {
+      const bool ok = b - a <= D->max_pair_dist;
+      return sf_hc_type(hc, ok ? D->pair[S[a]][S[b]] : 0, a, b, ok);
+    };
+    auto SCS = [&](int a, int b, int u1, int u2) -> int {
+      return (sc_rows && (u1 | u2) == 0) ? scS[a] + scS[a + 1] + scS[b - 1] + scS[b] : 0;
+    };
 
     for (int d = SFD_TURN + 1; d < W; d++) {
       const int i = tid + 1, j = i + d;
       if (j <= W) {
-        const int type = d <= D->max_pair_dist ? D->pair[S[i]][S[j]] : 0;  // max_bp_span
+        const int type = PTY(i, j);  // max_bp_span, hard constraint
         int cij = SFD_INF;
         if (type) {
           int e = sfd_hairpin(D, S, i, j, type);
@@ -70,9 +98,10 @@ __global__ void sf_mfe_full_kernel(const uint8_t *__restrict__ seqs, const int *
             const int p = i + 1 + u1;
             for (int u2 = 0; u2 <= umax - u1; u2++) {
               const int q = j - 1 - u2;
-              const int t2 = D->pair[S[p]][S[q]];
+              const int t2 = PTY(p, q);
               if (!t2) continue;
-              const int en = sfd_intloop(D, u1, u2, type, sfd_rtype(t2), si1, sj1, S[p - 1], S[q + 1]) + FT(c, q - p, p);
+              const int en = sfd_intloop(D, u1, u2, type, sfd_rtype(t2), si1, sj1, S[p - 1], S[q + 1]) + FT(c, q - p, p) +
+                             SCS(i, j, u1, u2);
               e = sfd_min(e, en);
             }
           }
@@ -102,7 +131,7 @@ __global__ void sf_mfe_full_kernel(const uint8_t *__restrict__ seqs, const int *
       int v = SFD_INF;
       const int i = tid + 1;
       if (i + SFD_TURN + 1 <= j && j - i <= D->max_pair_dist) {
-        const int type = D->pair[S[i]][S[j]];
+        const int type = PTY(i, j);
         if (type) v = f5s[i - 1] + FT(c, j - i, i) + sfd_extloop(D, type, i > 1 ? S[i - 1] : -1, j < W ? S[j + 1] : -1);
       }
       v = sf_block_min(v, red);
@@ -128,7 +157,7 @@ __global__ void sf_mfe_full_kernel(const uint8_t *__restrict__ seqs, const int *
           const int fij = f5s[j];
           int kk, found = 0;
           for (kk = j - SFD_TURN - 1; kk >= 1; kk--) {
-            const int type = j - kk <= D->max_pair_dist ? D->pair[S[kk]][S[j]] : 0;
+            const int type = PTY(kk, j);
             if (!type) continue;
             if (fij == f5s[kk - 1] + FT(c, j - kk, kk) +
                            sfd_extloop(D, type, kk > 1 ? S[kk - 1] : -1, j < W ? S[j + 1] : -1)) { found = 1; break; }
@@ -144,7 +173,7 @@ __global__ void sf_mfe_full_kernel(const uint8_t *__restrict__ seqs, const int *
           while (j - i > SFD_TURN + 1 && FT(fML, j - i - 1, i + 1) < SFD_INF &&
                  FT(fML, j - i, i) == FT(fML, j - i - 1, i + 1) + P.MLbase) i++;
           const int fij = FT(fML, j - i, i);
-          const int type = j - i <= D->max_pair_dist ? D->pair[S[i]][S[j]] : 0;
+          const int type = PTY(i, j);
           if (type && fij == FT(c, j - i, i) + sfd_mlstem(D, type, i > 1 ? S[i - 1] : -1, j < W ? S[j + 1] : -1)) {
             have_pair = true;
           } else {
@@ -161,7 +190,7 @@ __global__ void sf_mfe_full_kernel(const uint8_t *__restrict__ seqs, const int *
         while (have_pair) {
           db[i - 1] = '(';
           db[j - 1] = ')';
-          const int type = D->pair[S[i]][S[j]];
+          const int type = PTY(i, j);
           const int cij = FT(c, j - i, i);
           if (cij == sfd_hairpin(D, S, i, j, type)) break;
           const int d = j - i;
@@ -171,10 +200,10 @@ __global__ void sf_mfe_full_kernel(const uint8_t *__restrict__ seqs, const int *
             const int p = i + 1 + u1;
             for (int u2 = 0; u2 <= umax - u1; u2++) {
               const int q = j - 1 - u2;
-              const int t2 = D->pair[S[p]][S[q]];
+              const int t2 = PTY(p, q);
               if (!t2) continue;
               const int en = sfd_intloop(D, u1, u2, type, sfd_rtype(t2), S[i + 1], S[j - 1], S[p - 1], S[q + 1]) +
-                             FT(c, q - p, p);
+                             FT(c, q - p, p) + SCS(i, j, u1, u2);
               if (cij == en) { found = 1; fp = p; fq = q; break; }
             }
           }

@@ -39,7 +39,13 @@ __global__ void sf_pf_kernel(const uint8_t *__restrict__ seqs, int n, int row_st
                              const SfDevParams *__restrict__ D, const SfDevParamsPF *__restrict__ X,
                              double *__restrict__ scratch, double *__restrict__ ens_dG,
                              double *__restrict__ mean_bp_dist, char *__restrict__ centroid,
-                             double *__restrict__ centroid_dist) {
+                             double *__restrict__ centroid_dist, const char *__restrict__ cons_rows,
+                             int *__restrict__ status) {
+  // cons_rows: item k's hard constraint = W characters at cons_rows + k*W (fc.hc_add_from_db before fc.pf(),
+  // ScanFold-Scan.py:405-417); null = none
+  __shared__ char hcC[SF_MAX_W + 2];
+  __shared__ int16_t hcP[SF_MAX_W + 2], hcE[SF_MAX_W + 2], hcStk[SF_MAX_W + 2];
+  __shared__ int hcBad;
   __shared__ uint8_t S[SF_MAX_W + 2];
   __shared__ double q5[SF_MAX_W + 2];
   __shared__ double q3[SF_MAX_W + 3];
@@ -59,13 +65,24 @@ __global__ void sf_pf_kernel(const uint8_t *__restrict__ seqs, int n, int row_st
     for (int x = tid; x < W; x += nthreads) S[x + 1] = sf_encode_nt(src[x]);
     if (tid == 0) { S[0] = 0; S[W + 1] = 0; }
     for (size_t x = tid; x < (size_t)4 * W1 && x < TS; x += nthreads) { QB[x] = 0.0; QM[x] = 0.0; QM1[x] = 0.0; }
+    SfHc hc;
+    hc.c = cons_rows ? hcC : nullptr; hc.partner = hcP; hc.encl = hcE;
+    if (cons_rows && tid == 0) hcBad = sf_hc_parse(cons_rows + (size_t)k * W, W, hcC, hcP, hcE, hcStk);
     __syncthreads();
+    if (cons_rows && hcBad) {  // unbalanced brackets
+      if (tid == 0 && status) atomicOr(status, 2);
+      continue;
+    }
+    auto PTY = [&](int a, int b) -> int {
+      const bool ok = b - a <= D->max_pair_dist;
+      return sf_hc_type(hc, ok ? D->pair[S[a]][S[b]] : 0, a, b, ok);
+    };
 
     // ---------------- inside ----------------
     for (int d = SFD_TURN + 1; d < W; d++) {
       const int i = tid + 1, j = i + d;
       if (j <= W) {
-        const int type = j - i <= D->max_pair_dist ? D->pair[S[i]][S[j]] : 0;
+        const int type = PTY(i, j);
         double qbij = 0.0;
         if (type) {
           double z = sfx_hairpin(D, X, S, i, j, type);
@@ -75,7 +92,7 @@ __global__ void sf_pf_kernel(const uint8_t *__restrict__ seqs, int n, int row_st
             const int p = i + 1 + u1;
             for (int u2 = 0; u2 <= umax - u1; u2++) {
               const int q = j - 1 - u2;
-              const int t2 = D->pair[S[p]][S[q]];
+              const int t2 = PTY(p, q);
               if (!t2) continue;
               z += sfx_intloop(X, u1, u2, type, sfd_rtype(t2), si1, sj1, S[p - 1], S[q + 1]) * PT(QB, q - p, p);
             }
@@ -103,7 +120,7 @@ __global__ void sf_pf_kernel(const uint8_t *__restrict__ seqs, int n, int row_st
       double v = 0.0;
       const int i = tid + 1;
       if (i + SFD_TURN + 1 <= j) {
-        const int type = j - i <= D->max_pair_dist ? D->pair[S[i]][S[j]] : 0;
+        const int type = PTY(i, j);
         if (type) v = q5[i - 1] * PT(QB, j - i, i) * sfx_extloop(X, type, i > 1 ? S[i - 1] : -1, j < W ? S[j + 1] : -1);
       }
       v = sf_block_sum(v, red);
@@ -114,7 +131,7 @@ __global__ void sf_pf_kernel(const uint8_t *__restrict__ seqs, int n, int row_st
       double v = 0.0;
       const int j = tid + 1;
       if (j <= W && i + SFD_TURN + 1 <= j) {
-        const int type = j - i <= D->max_pair_dist ? D->pair[S[i]][S[j]] : 0;
+        const int type = PTY(i, j);
         if (type) v = PT(QB, j - i, i) * sfx_extloop(X, type, i > 1 ? S[i - 1] : -1, j < W ? S[j + 1] : -1) * q3[j + 1];
       }
       v = sf_block_sum(v, red);
@@ -135,7 +152,7 @@ __global__ void sf_pf_kernel(const uint8_t *__restrict__ seqs, int n, int row_st
         }
         PT(A0, d, i) = a0;
         PT(A1, d, i) = a1;
-        const int type = j - i <= D->max_pair_dist ? D->pair[S[i]][S[j]] : 0;
+        const int type = PTY(i, j);
         double o = 0.0, ow = 0.0;
         const double qbij = PT(QB, d, i);
         if (type && qbij != 0.0) {
@@ -149,7 +166,7 @@ __global__ void sf_pf_kernel(const uint8_t *__restrict__ seqs, int n, int row_st
               const int u2max = sfd_min(SFD_MAXLOOP - u1, W - j - 1);
               for (int u2 = 0; u2 <= u2max; u2++) {
                 const int l = j + 1 + u2;
-                const int tk = D->pair[S[kk]][S[l]];
+                const int tk = PTY(kk, l);
                 if (!tk) continue;
                 o += PT(OB, l - kk, kk) * sfx_intloop(X, u1, u2, tk, rt, S[kk + 1], S[l - 1], sp1, sq1);
               }

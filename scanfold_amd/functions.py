@@ -146,10 +146,7 @@ def energies(seq_list, temperature=37, algo="rnafold"):
         # the reference leaves MFE unbound for any other algo (ScanFoldFunctions.py:785-789)
         raise UnboundLocalError("local variable 'MFE' referenced before assignment")
     eng = _lib.get_engine()
-    if float(int(temperature)) != eng.params.temperature:
-        raise NotImplementedError(
-            "folding temperature %s C: the loaded parameter set is valid at %s C only"
-            % (temperature, eng.params.temperature))
+    eng.set_temperature(int(temperature))  # md.temperature = int(temperature), ScanFoldFunctions.py:776-777
     seqs = [str(s) for s in seq_list]
     out = [None] * len(seqs)
     by_len = {}

@@ -50,22 +50,69 @@ _MM_SECTIONS = {
 }
 
 
-class ParamSet:
-    """One parameter set; `.rec` is a numpy record with the fields of sf_params_blob."""
+K0 = 273.15
+T_MEASURE = 37.0 + K0
 
-    def __init__(self, rec, source):
+# free-energy field -> what is rescaled with it (all fields that have an enthalpy twin in a .par file)
+_RESCALED = ("stack", "hairpin", "bulge", "internal_loop", "mismatchI", "mismatchH", "mismatchM", "mismatch1nI",
+             "mismatch23I", "mismatchExt", "dangle5", "dangle3", "int11", "int21", "int22", "ninio", "MLbase",
+             "MLclosing", "MLintern", "TerminalAU", "DuplexInit", "tetra_E", "tri_E", "hexa_E")
+
+
+class ParamSet:
+    """One parameter set; `.rec` is a numpy record with the fields of sf_params_blob (free energies at
+    `.temperature`), `.dH` — when the source file had `*_enthalpies` sections — the same record holding enthalpies,
+    `.rec37` the free energies at 37 C the set was read with."""
+
+    def __init__(self, rec, source, dH=None, rec37=None, lxc37=None):
         self.rec = rec
         self.source = source
+        self.dH = dH
+        self.rec37 = rec37 if rec37 is not None else rec
+        self.lxc37 = float(rec["lxc"]) if lxc37 is None else lxc37
 
     def blob(self):
-        return self.rec.tobytes()
+        out = np.zeros((), dtype=BLOB_DTYPE)  # deterministic padding bytes (numpy leaves them undefined on copies)
+        for f in BLOB_DTYPE.names:
+            out[f] = self.rec[f]
+        return out.tobytes()
 
     @property
     def temperature(self):
         return float(self.rec["temperature"])
 
     def copy(self):
-        return ParamSet(self.rec.copy(), self.source)
+        return ParamSet(self.rec.copy(), self.source, None if self.dH is None else self.dH.copy(),
+                        None if self.rec37 is self.rec else self.rec37.copy(), self.lxc37)
+
+    def at_temperature(self, temperature_c):
+        """The set rescaled to another temperature the way ViennaRNA's get_scaled_params does it [EXT]:
+        dG(T) = dH - (dH - dG37) * (T + K0) / (37 + K0), computed in double and truncated towards zero (the C code
+        assigns the double to an int); lxc scales linearly; the MFE model later clamps dangles / multiloop and
+        exterior mismatches to <= 0 (sf_params_load).  Needs the enthalpy sections of a real .par file: the
+        reconstructed default set has none (RNA.md().temperature, ScanFold-Scan.py:70-71; ScanFoldFunctions.py:776-777)."""
+        t = float(temperature_c)
+        if abs(t - 37.0) < 1e-12:
+            base = ParamSet(self.rec37.copy(), self.source, self.dH, None, self.lxc37)
+            return base
+        if self.dH is None:
+            raise NotImplementedError(
+                "folding temperature %s C: parameter set %s has no enthalpy tables (it is valid at 37 C only); load a "
+                "ViennaRNA .par file that has *_enthalpies sections" % (temperature_c, self.source))
+        tempf = (t + K0) / T_MEASURE
+        out = self.rec37.copy()
+        for f in _RESCALED:
+            g37 = self.rec37[f].astype(np.float64)
+            dh = self.dH[f].astype(np.float64)
+            v = np.trunc(dh - (dh - g37) * tempf)
+            v = np.where(np.abs(self.rec37[f]) >= INF, self.rec37[f], v)  # INF stays INF
+            out[f] = v.astype(np.int64)
+        out["lxc"] = self.lxc37 * tempf
+        out["temperature"] = t
+        return ParamSet(out, self.source, self.dH, self.rec37, self.lxc37)
+
+
+_DEF = -(1 << 40)  # marker of a "DEF" token: keep the default value of that entry
 
 
 def _tok_int(t):
@@ -74,11 +121,63 @@ def _tok_int(t):
     if t == "-INF":
         return -INF
     if t == "DEF":
-        raise ValueError("DEF entries are not supported (no compiled-in defaults to fall back on)")
+        return _DEF
     return int(t)
 
 
-def parse_par_text(text, source="<string>"):
+def _fill_sections(sections, rec, suffix, source, defaults):
+    """Fill `rec` from the sections `<name><suffix>` (suffix "" = free energies, "_enthalpies" = enthalpies).
+    A "DEF" token keeps the entry of `defaults` (ViennaRNA keeps its compiled-in value there; here the shipped
+    default set stands in, which is only right for the entries the two sets share)."""
+    def ints(name, n):
+        toks = " ".join(sections[name + suffix]).split()
+        if len(toks) != n:
+            raise ValueError("%s: section '%s' has %d values, expected %d" % (source, name + suffix, len(toks), n))
+        return np.array([_tok_int(t) for t in toks], dtype=np.int64)
+
+    def put(field, index, values):
+        dst = rec[field][index]
+        if (values == _DEF).any():
+            if defaults is None:
+                raise ValueError("%s: DEF entries in '%s' but no default set to take them from" % (source, field))
+            values = np.where(values == _DEF, defaults[field][index], values)
+        rec[field][index] = values.reshape(dst.shape)
+
+    put("stack", np.s_[1:8, 1:8], ints("stack", 49).reshape(7, 7))
+    for sec, field in _MM_SECTIONS.items():
+        put(field, np.s_[1:8], ints(sec, 175).reshape(7, 5, 5))
+    put("dangle5", np.s_[1:8], ints("dangle5", 35).reshape(7, 5))
+    put("dangle3", np.s_[1:8], ints("dangle3", 35).reshape(7, 5))
+    put("int11", np.s_[1:8, 1:8], ints("int11", 49 * 25).reshape(7, 7, 5, 5))
+    put("int21", np.s_[1:8, 1:8], ints("int21", 49 * 125).reshape(7, 7, 5, 5, 5))
+    core = ints("int22", 36 * 256).reshape(6, 6, 4, 4, 4, 4)
+    if (core == _DEF).any():
+        if defaults is None:
+            raise ValueError("%s: DEF entries in 'int22' but no default set to take them from" % source)
+        core = np.where(core == _DEF, defaults["int22"][1:7, 1:7, 1:5, 1:5, 1:5, 1:5], core)
+    i22 = np.zeros((8, 8, 5, 5, 5, 5), dtype=np.int64)
+    i22[1:7, 1:7, 1:5, 1:5, 1:5, 1:5] = core
+    # entries with an unknown base (index 0) / non-standard pair (7): least stabilising known entry
+    for ax in (2, 3, 4, 5):
+        sl = [slice(None)] * 6
+        sl[ax] = slice(1, 5)
+        dst = [slice(None)] * 6
+        dst[ax] = 0
+        i22[tuple(dst)] = i22[tuple(sl)].max(axis=ax)
+    i22[7, :] = i22[1:7, :].max(axis=0)
+    i22[:, 7] = i22[:, 1:7].max(axis=1)
+    i22[0, :] = 0
+    i22[:, 0] = 0
+    rec["int22"] = i22
+    put("hairpin", np.s_[:], ints("hairpin", 31))
+    put("bulge", np.s_[:], ints("bulge", 31))
+    put("internal_loop", np.s_[:], ints("interior", 31))
+
+
+def parse_par_text(text, source="<string>", defaults="shipped"):
+    """ViennaRNA "RNAfold parameter file v2.0" text -> ParamSet.  Sections are `# name` lines; `/* ... */` comments
+    (also spanning lines) and `##` lines are skipped; `_enthalpies` sections, when all present, are kept for
+    ParamSet.at_temperature; "DEF" entries fall back to `defaults` ("shipped": the set of this package, None: error)."""
     if not text.lstrip().startswith("## RNAfold parameter file v2.0"):
         raise ValueError("%s: not a 'RNAfold parameter file v2.0'" % source)
     text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
@@ -97,59 +196,58 @@ def parse_par_text(text, source="<string>"):
         if cur is not None:
             sections[cur].append(line)
 
+    def_rec = None
+    if defaults == "shipped":
+        if os.path.abspath(str(source)) != os.path.abspath(DEFAULT_PAR) and "DEF" in text.split():
+            def_rec = default_params().rec37
+    elif defaults is not None:
+        def_rec = defaults.rec37
+
     rec = np.zeros((), dtype=BLOB_DTYPE)
     rec["magic"] = MAGIC
     rec["version"] = VERSION
     rec["temperature"] = 37.0
 
-    def ints(name, n):
-        toks = " ".join(sections[name]).split()
-        if len(toks) != n:
-            raise ValueError("%s: section '%s' has %d values, expected %d" % (source, name, len(toks), n))
-        return np.array([_tok_int(t) for t in toks], dtype=np.int64)
-
-    need = ["stack", "hairpin", "bulge", "interior", "dangle5", "dangle3", "int11", "int21", "int22",
-            "NINIO", "ML_params", "Misc"] + list(_MM_SECTIONS)
+    table_secs = ["stack", "hairpin", "bulge", "interior", "dangle5", "dangle3", "int11", "int21", "int22"] + \
+        list(_MM_SECTIONS)
+    need = table_secs + ["NINIO", "ML_params", "Misc"]
     missing = [s for s in need if s not in sections]
     if missing:
         raise ValueError("%s: missing sections %s" % (source, missing))
+    _fill_sections(sections, rec, "", source, def_rec)
 
-    rec["stack"][1:8, 1:8] = ints("stack", 49).reshape(7, 7)
-    for sec, field in _MM_SECTIONS.items():
-        rec[field][1:8] = ints(sec, 175).reshape(7, 5, 5)
-    rec["dangle5"][1:8] = ints("dangle5", 35).reshape(7, 5)
-    rec["dangle3"][1:8] = ints("dangle3", 35).reshape(7, 5)
-    rec["int11"][1:8, 1:8] = ints("int11", 49 * 25).reshape(7, 7, 5, 5)
-    rec["int21"][1:8, 1:8] = ints("int21", 49 * 125).reshape(7, 7, 5, 5, 5)
-    core = ints("int22", 36 * 256).reshape(6, 6, 4, 4, 4, 4)
-    i22 = np.zeros((8, 8, 5, 5, 5, 5), dtype=np.int64)
-    i22[1:7, 1:7, 1:5, 1:5, 1:5, 1:5] = core
-    # entries with an unknown base (index 0) / non-standard pair (7): least stabilising known entry
-    for ax in (2, 3, 4, 5):
-        sl = [slice(None)] * 6
-        sl[ax] = slice(1, 5)
-        dst = [slice(None)] * 6
-        dst[ax] = 0
-        i22[tuple(dst)] = i22[tuple(sl)].max(axis=ax)
-    i22[7, :] = i22[1:7, :].max(axis=0)
-    i22[:, 7] = i22[:, 1:7].max(axis=1)
-    i22[0, :] = 0
-    i22[:, 0] = 0
-    rec["int22"] = i22
-    rec["hairpin"] = ints("hairpin", 31)
-    rec["bulge"] = ints("bulge", 31)
-    rec["internal_loop"] = ints("interior", 31)
-    nin = " ".join(sections["NINIO"]).split()
-    rec["ninio"] = _tok_int(nin[0])
-    rec["max_ninio"] = _tok_int(nin[2])
-    ml = " ".join(sections["ML_params"]).split()
-    rec["MLbase"] = _tok_int(ml[0])
-    rec["MLclosing"] = _tok_int(ml[2])
-    rec["MLintern"][:] = _tok_int(ml[4])
-    misc = " ".join(sections["Misc"]).split()
-    rec["DuplexInit"] = _tok_int(misc[0])
-    rec["TerminalAU"] = _tok_int(misc[2])
+    have_dh = all((s + "_enthalpies") in sections for s in table_secs)
+    dH = None
+    if have_dh:
+        dH = np.zeros((), dtype=BLOB_DTYPE)
+        _fill_sections(sections, dH, "_enthalpies", source, None)
+
+    def scalar(tok, field, index=None):
+        v = _tok_int(tok)
+        if v == _DEF:
+            if def_rec is None:
+                raise ValueError("%s: DEF entry for %s but no default set" % (source, field))
+            v = int(def_rec[field] if index is None else def_rec[field][index])
+        return v
+
+    nin = " ".join(sections["NINIO"]).split()       # m  m_dH  max
+    rec["ninio"] = scalar(nin[0], "ninio")
+    rec["max_ninio"] = scalar(nin[2], "max_ninio")
+    ml = " ".join(sections["ML_params"]).split()    # cu cu_dH cc cc_dH ci ci_dH
+    rec["MLbase"] = scalar(ml[0], "MLbase")
+    rec["MLclosing"] = scalar(ml[2], "MLclosing")
+    rec["MLintern"][:] = scalar(ml[4], "MLintern", 1)
+    misc = " ".join(sections["Misc"]).split()       # DuplexInit dH TerminalAU dH [lxc lxc_dH]
+    rec["DuplexInit"] = scalar(misc[0], "DuplexInit")
+    rec["TerminalAU"] = scalar(misc[2], "TerminalAU")
     rec["lxc"] = float(misc[4]) if len(misc) > 4 else 107.856
+    if dH is not None:
+        dH["ninio"] = _tok_int(nin[1])
+        dH["MLbase"] = _tok_int(ml[1])
+        dH["MLclosing"] = _tok_int(ml[3])
+        dH["MLintern"][:] = _tok_int(ml[5])
+        dH["DuplexInit"] = _tok_int(misc[1])
+        dH["TerminalAU"] = _tok_int(misc[3])
 
     for sec, fseq, fe, fn, ln in (("Tetraloops", "tetra_seq", "tetra_E", "n_tetra", 6),
                                   ("Triloops", "tri_seq", "tri_E", "n_tri", 5),
@@ -165,9 +263,14 @@ def parse_par_text(text, source="<string>"):
                 raise ValueError("%s: more than %d %s" % (source, MAX_SPECIAL, sec))
             rec[fseq][k] = parts[0].encode()
             rec[fe][k] = _tok_int(parts[1])
+            if dH is not None:
+                if len(parts) < 3:
+                    dH = None  # a special loop without an enthalpy: the set cannot be rescaled
+                else:
+                    dH[fe][k] = _tok_int(parts[2])
             k += 1
         rec[fn] = k
-    return ParamSet(rec, source)
+    return ParamSet(rec, source, dH)
 
 
 def load_par(path):

@@ -16,9 +16,9 @@ The per-window arithmetic (:382-423) is one `sf_scan` call per record for ALL wi
 structure, partition function -> centroid / ensemble diversity, r shuffles, r+1 MFE folds.
 
 Deliberate differences (documented in DESIGN.md): shuffles come from the device generator
-(`--shuffle-backend python` restores the reference's `random`-module shuffles), constraints (-c) and
-temperatures other than the parameter set's are rejected instead of silently half-applied
-(SURVEY.md F8), and extra flags --seed/--params/--shuffle-backend/-o exist.
+(`--shuffle-backend python` restores the reference's `random`-module shuffles); extra flags
+--seed/--params/--shuffle-backend/--span/--gpus/--constraint-unbalanced/-o exist.  -t and -c behave as upstream
+(SURVEY.md F8): they change the native window's fold only; -t needs a parameter set with enthalpy tables.
 """
 import argparse
 import os
@@ -91,7 +91,8 @@ def _text_rows(x, W):
     return x
 
 
-def rows_from_results(seq, starts, W, r, temperature, energies_dcal, structures, centroids, ens_div):
+def rows_from_results(seq, starts, W, r, temperature, energies_dcal, structures, centroids, ens_div,
+                      native_dcal=None):
     """TSV rows for the given windows from raw engine output; rounding exactly as the reference does it
     (ScanFold-Scan.py:386,389,426-433,442).  No per-row numpy objects: the columns are rounded and converted to
     text as whole lists (np.round on a vector equals round() on each np.float64, str(float) equals
@@ -102,7 +103,10 @@ def rows_from_results(seq, starts, W, r, temperature, energies_dcal, structures,
     tseq = transcribe(seq)
     n = len(starts)
     t = str(temperature)
-    mfe_s = [str(round(v, 2)) for v in E[:, 0].tolist()]
+    # Native_dG column: the energy of the native fold as the reference computed it — with -t / -c that fold differs
+    # from energy_list[0], which stays the plain 37 C RNA.fold of the window (ScanFold-Scan.py:244-246,382-398)
+    nat = E[:, 0] if native_dcal is None else dcal_to_float(native_dcal)
+    mfe_s = [str(round(v, 2)) for v in nat.tolist()]
     z_s = [str(v) for v in np.round(z, 2).tolist()]  # np.float64.__round__, as upstream's np.mean-derived value
     if sd0.any():
         for k in np.nonzero(sd0)[0].tolist():
@@ -126,25 +130,24 @@ def rows_from_results(seq, starts, W, r, temperature, energies_dcal, structures,
 CHUNK_WINDOWS = 4096  # windows per engine call: the host formats chunk k while the GPU computes chunk k+1
 
 
-def _engine_chunks(eng, seq, W, step, n_win, r, kind, seed, lo=0, hi=None, chunk=None, threaded=True):
-    """Yield (w0, result) for consecutive chunks of windows [lo, hi).  The engine calls run on a helper thread
-    (ctypes drops the GIL for the duration of sf_scan), so the caller's work on chunk k overlaps chunk k+1 on
-    the GPU.  Only that thread talks to the library while the generator is alive."""
+def _engine_chunks(work, lo, hi, chunk=None, threaded=True):
+    """Yield (w0, work(w0, nw)) for consecutive chunks of windows [lo, hi).  `work` makes the engine calls; it runs
+    on a helper thread (ctypes drops the GIL for the duration of a library call), so the caller's host work on
+    chunk k overlaps chunk k+1 on the GPU.  Only that thread talks to the library while the generator is alive."""
     import queue
     import threading
-    hi = n_win if hi is None else hi
     chunk = chunk or int(os.environ.get("SCANFOLD_CHUNK_WINDOWS", CHUNK_WINDOWS))
     bounds = [(w0, min(chunk, hi - w0)) for w0 in range(lo, hi, chunk)]
     if not threaded or len(bounds) <= 1:
         for w0, nw in bounds:
-            yield w0, eng.scan(seq, W, step, w0, nw, r, kind, seed, raw=True)
+            yield w0, work(w0, nw)
         return
     q = queue.Queue(maxsize=2)
 
     def produce():
         try:
             for w0, nw in bounds:
-                q.put((w0, eng.scan(seq, W, step, w0, nw, r, kind, seed, raw=True)))
+                q.put((w0, work(w0, nw)))
         except BaseException as e:  # hand the error to the consumer
             q.put((None, e))
         q.put((None, None))
@@ -161,24 +164,71 @@ def _engine_chunks(eng, seq, W, step, n_win, r, kind, seed, lo=0, hi=None, chunk
         yield w0, res
 
 
+def read_constraints(path, seq_len):
+    """The -c file as ScanFold-Scan.py:312-333 reads it: its THIRD line is the dot-bracket constraint of the whole
+    record; upstream compares len(line incl. newline) - 1 with the sequence length and raises otherwise."""
+    with open(path, "r") as f:
+        constraints = f.readlines()[2]
+    print("Constraint list is " + str(len(constraints) - 1) + "nt long.")
+    if len(constraints) - 1 != seq_len:
+        raise ValueError("Error detected. Sequence and Constraints must be same length.")
+    return constraints[:seq_len]
+
+
+def _window_rows(text, W, step, w0, nw):
+    """uint8 (nw, W): windows w0 .. w0+nw-1 of `text`."""
+    arr = np.frombuffer(text.encode("ascii"), dtype=np.uint8)
+    view = np.lib.stride_tricks.sliding_window_view(arr, W)[::step]
+    return np.ascontiguousarray(view[w0:w0 + nw])
+
+
 def scan_record(seq, W, step, r, shuffle_type, temperature=37, engine=None, seed=0, shuffle_backend="device",
-                print_random=False, chunk=None):
-    """All windows of one record -> list of TSV row strings."""
+                print_random=False, chunk=None, constraints=None, unbalanced="error"):
+    """All windows of one record -> list of TSV row strings.
+
+    temperature / constraints follow ScanFold-Scan.py: the native window's MFE, structure, centroid and
+    ensemble diversity honour -t and -c (fc = RNA.fold_compound(frag, md); fc.hc_add_from_db(...), :382-418), while
+    the r shuffles AND the native energy that enters the z-score come from the global RNA.fold — 37 C, unconstrained
+    (:244-246,419-433).  constraints: the record's dot-bracket line (read_constraints), sliced per window as :405-406.
+    unbalanced: what to do when a window cuts through a bracket pair — "error" (ViennaRNA aborts there) or "ignore"
+    (the unmatched brackets of that window become '.')."""
     eng = engine if engine is not None else _lib.get_engine()
-    if float(int(temperature)) != eng.params.temperature:
-        raise NotImplementedError("folding temperature %s C: parameter set valid at %s C only"
-                                  % (temperature, eng.params.temperature))
     if shuffle_type not in ("di", "mono"):
         # upstream prints a message and goes on with zero shuffles (NaN z-scores); refuse instead
         raise ValueError('Shuffle type not properly designated; please input "di" or "mono"')
+    if shuffle_backend not in ("device", "python"):
+        raise ValueError("shuffle_backend must be 'device' or 'python'")
+    temperature = int(temperature)
+    plain = constraints is None and temperature == 37
+    if not plain:
+        eng.set_temperature(temperature)  # fails early for a parameter set without enthalpies
     starts = window_starts(len(seq), W, step)
     n_win = len(starts)
     kind = _lib.SHUFFLE_DI if shuffle_type == "di" else _lib.SHUFFLE_MONO
-    if shuffle_backend not in ("device", "python"):
-        raise ValueError("shuffle_backend must be 'device' or 'python'")
+    r_dev = r if shuffle_backend == "device" else 0
+
+    def work(w0, nw):
+        if plain:
+            eng.set_temperature(37)
+            return eng.scan(seq, W, step, w0, nw, r_dev, kind, seed, raw=True)
+        eng.set_temperature(37)
+        out = dict(energies=eng.scan(seq, W, step, w0, nw, r_dev, kind, seed, _lib.SCAN_NO_PF | _lib.SCAN_NO_TRACE,
+                                     raw=True)["energies"])
+        eng.set_temperature(temperature)
+        if constraints is None:
+            nat = eng.scan(seq, W, step, w0, nw, 0, kind, seed, raw=True)
+            out.update(native=nat["energies"][:, 0], structure=nat["structure"], centroid=nat["centroid"],
+                       ens_div=nat["ens_div"])
+        else:
+            cons = _window_rows(constraints, W, step, w0, nw)
+            if unbalanced == "ignore":
+                cons = _drop_unmatched_brackets(cons)
+            fc = eng.fold_constrained(_window_rows(transcribe(seq), W, step, w0, nw), cons)
+            out.update(native=fc["mfe"], structure=fc["structure"], centroid=fc["centroid"], ens_div=fc["mean_bp_dist"])
+        return out
+
     rows = []
-    for w0, res in _engine_chunks(eng, seq, W, step, n_win, r if shuffle_backend == "device" else 0, kind, seed,
-                                  chunk=chunk, threaded=(shuffle_backend == "device")):
+    for w0, res in _engine_chunks(work, 0, n_win, chunk=chunk, threaded=(shuffle_backend == "device")):
         sub = starts[w0:w0 + len(res["ens_div"])]
         energies_dcal = res["energies"]
         if shuffle_backend == "python":
@@ -188,13 +238,33 @@ def scan_record(seq, W, step, r, shuffle_type, temperature=37, engine=None, seed
                 frag = transcribe(seq[i:i + W])
                 rows_seq.append(frag)
                 rows_seq.extend(sfn.scramble(frag, r, shuffle_type))
+            eng.set_temperature(37)
             energies_dcal = eng.mfe_batch(rows_seq).reshape(len(sub), r + 1)
         if print_random:
             for k in range(len(sub)):
                 print([float(v) for v in dcal_to_float(energies_dcal[k])])
         rows.extend(rows_from_results(seq, sub, W, r, temperature, energies_dcal, res["structure"], res["centroid"],
-                                      res["ens_div"]))
+                                      res["ens_div"], native_dcal=res.get("native")))
     return rows
+
+
+def _drop_unmatched_brackets(cons):
+    """uint8 (n, W) constraint rows: brackets without a partner inside their window -> '.' (the `--constraint-unbalanced
+    ignore` policy; upstream would abort inside ViennaRNA on such a window)."""
+    cons = cons.copy()
+    for row in cons:
+        stack = []
+        for k, ch in enumerate(row):
+            if ch == 40:
+                stack.append(k)
+            elif ch == 41:
+                if stack:
+                    stack.pop()
+                else:
+                    row[k] = 46
+        for k in stack:
+            row[k] = 46
+    return cons
 
 
 def scan_record_sharded(seq, W, step, r, shuffle_type, temperature, eng, seed, rank, world):
@@ -231,6 +301,9 @@ def build_parser():
     parser.add_argument('--seed', type=int, default=0, help='seed of the device shuffle generator')
     parser.add_argument('--shuffle-backend', choices=("device", "python"), default="device")
     parser.add_argument('--params', type=str, default=None, help='ViennaRNA .par (v2.0) file to use')
+    parser.add_argument('--constraint-unbalanced', choices=("error", "ignore"), default="error",
+                        help='a window that cuts through a bracket pair of the -c line: error (ViennaRNA aborts '
+                        'there, the default) or ignore (the unmatched brackets of that window become dots)')
     parser.add_argument('--require-published-params', action='store_true',
                         help='refuse to run on the reconstructed default parameter set (needs --params)')
     parser.add_argument('--gpus', type=int, default=1, help='shard the windows of every record over this many GPUs '
@@ -258,8 +331,6 @@ def main(argv=None):
     args = build_parser().parse_args(argv)
     if not args.filename:
         raise SystemExit("-i/--filename is required")
-    if args.constraints is not None:
-        raise NotImplementedError("hard constraints (-c) are not supported by the HIP engine yet")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -295,13 +366,20 @@ def main(argv=None):
                 print("Scanning sequence " + str(read_name) + "\nSequence Length: " + str(len(seq)) + "nt long.")
             if len(seq) < window_size:
                 continue
+            constraints = None
+            if args.constraints is not None:
+                print("Considering constraint input")
+                constraints = read_constraints(args.constraints, len(seq))
             if world > 1:
+                if constraints is not None or temperature != 37:
+                    raise SystemExit("--gpus > 1 supports the plain scan only (no -c, -t 37)")
                 rows = scan_record_sharded(seq, window_size, step_size, randomizations, shuffle_type, temperature,
                                            eng, args.seed, rank, world)
             else:
                 rows = scan_record(seq, window_size, step_size, randomizations, shuffle_type, temperature, eng,
                                    seed=args.seed, shuffle_backend=args.shuffle_backend,
-                                   print_random=(args.print_random == "on"))
+                                   print_random=(args.print_random == "on"), constraints=constraints,
+                                   unbalanced=args.constraint_unbalanced)
             if rank != 0:
                 continue
             w.write(header_line(read_name))

@@ -450,3 +450,75 @@ def test_scan_step_one_shares_inside_tables(gpu_engine, oracle):
         o = oracle.pf(wins[w])
         assert o["centroid"] == res["centroid"][w], w
         assert abs(o["mean_bp_dist"] - res["ens_div"][w]) < PF_TOL and abs(o["dG"] - res["ens_dG"][w]) < PF_TOL, w
+
+
+def test_constrained_native_folds_match_oracle(gpu_engine, oracle):
+    """sf_fold_constrained (fc.hc_add_from_db / fc.sc_add_SHAPE_deigan, ScanFold-Scan.py:405-418; ScanFold.py:508-544):
+    the general int32 / FP64 kernels under a per-window constraint, 300 windows of W=120 and smaller shapes."""
+    from test_constraints import random_constraint, rseq
+    rng = np.random.default_rng(77)
+    try:
+        for W, n, use_sc in ((120, 300, False), (120, 60, True), (45, 64, True), (200, 12, False)):
+            seqs = [rseq(rng, W) for _ in range(n)]
+            cons = [random_constraint(rng, W, 4) for _ in range(n)]
+            sc = rng.integers(-60, 40, (n, W)).astype(np.int32) if use_sc else None
+            r = gpu_engine.fold_constrained(seqs, cons, sc)
+            for k in range(0, n, 1 if n <= 64 else 5):
+                oracle.set_constraint(cons[k], None if sc is None else sc[k])
+                assert oracle.mfe(seqs[k]) == (r["structure"][k], int(r["mfe"][k])), (W, k)
+                oracle.set_constraint(cons[k], None)
+                o = oracle.pf(seqs[k])
+                assert o["centroid"] == r["centroid"][k]
+                assert abs(o["dG"] - r["dG"][k]) < PF_TOL and abs(o["mean_bp_dist"] - r["mean_bp_dist"][k]) < PF_TOL
+        oracle.set_constraint(None, None)
+        seqs = [rseq(rng, 120) for _ in range(50)]
+        e, db = gpu_engine.mfe_trace_batch(seqs)
+        r = gpu_engine.fold_constrained(seqs, ["." * 120] * 50)
+        assert (r["mfe"] == e).all() and r["structure"] == db
+        with pytest.raises(_lib.ScanFoldHipError, match="unbalanced"):
+            gpu_engine.fold_constrained(seqs[:2], ["." * 120, "(" + "." * 119])
+        # the CLI path: constrained native fold, unconstrained z-score (SURVEY.md F8)
+        seq = synth_transcript(400, 5)
+        cons = ("." * 30 + "((((((......))))))" + "xxxx" + "<<<<....>>>>" + "." * 336)[:400]
+        rows = scanmod.scan_record(seq, 120, 20, 10, "di", 37, gpu_engine, seed=2, constraints=cons, unbalanced="ignore")
+        plain = scanmod.scan_record(seq, 120, 20, 10, "di", 37, gpu_engine, seed=2)
+        for k, (a, b) in enumerate(zip(rows, plain)):
+            a, b = a.rstrip("\n").split("\t"), b.rstrip("\n").split("\t")
+            assert a[4:6] == b[4:6]
+            wc = bytes(scanmod._drop_unmatched_brackets(
+                np.frombuffer(cons[20 * k:20 * k + 120].encode(), dtype=np.uint8)[None, :].copy())[0]).decode()
+            oracle.set_constraint(wc, None)
+            db1, e1 = oracle.mfe(seq[20 * k:20 * k + 120])
+            assert a[8] == db1 and a[3] == str(round(float(np.float32(e1) / np.float32(100)), 2))
+    finally:
+        oracle.set_constraint(None, None)
+
+
+def test_temperature_rescale_on_gpu(gpu_engine, oracle):
+    """md.temperature != 37 (ScanFold-Scan.py:70-71; ScanFoldFunctions.py:776-777) with a parameter file that has
+    enthalpy sections (synthetic, in the published layout): every kernel of the hot path at 25 C and 50 C."""
+    from par_util import par_text, synthetic_enthalpies
+    base = params.default_params()
+    p = params.parse_par_text(par_text(base.rec, synthetic_enthalpies(base.rec, 9)), source="synthetic.par")
+    rng = np.random.default_rng(25)
+    try:
+        gpu_engine.load_params(p)
+        for T in (25, 50):
+            gpu_engine.set_temperature(T)
+            oracle.set_params(p.at_temperature(T))
+            arr = random_seqs(rng, 1500, 120)
+            assert (gpu_engine.mfe_batch(arr) == oracle.mfe_batch(arr)).all(), T
+            e, db = gpu_engine.mfe_trace_batch(arr[:40])
+            r = gpu_engine.pf_batch(arr[:40])
+            for k in range(40):
+                s = bytes(arr[k]).decode()
+                assert (db[k], int(e[k])) == oracle.mfe(s)
+                o = oracle.pf(s)
+                assert o["centroid"] == r["centroid"][k] and abs(o["dG"] - r["dG"][k]) < PF_TOL
+                assert abs(o["mean_bp_dist"] - r["mean_bp_dist"][k]) < PF_TOL
+        gpu_engine.load_params(base)
+        with pytest.raises(NotImplementedError):
+            gpu_engine.set_temperature(25)
+    finally:
+        oracle.set_params(base)
+        gpu_engine.load_params(base)

@@ -1,0 +1,111 @@
+"""The ScanFold.py flavour of the scan (ScanFoldFunctions z-score, GC-content column) and the scan -> fold pipeline.
+Row and header strings are pinned by the reference's own expressions (tests/golden/scanfold_py_rows.json, made by
+tests/golden/make_golden_scanfold_rows.py); the engine underneath is the kernel source compiled for the CPU."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from scanfold_amd import _lib, fold, functions as sff, params
+from scanfold_amd import scanfold as sfd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def emul():
+    from emul_engine import emul_engine
+    e = emul_engine()
+    e.load_params(params.default_params())
+    return e
+
+
+def test_rows_match_the_reference_expressions():
+    items = json.load(open(os.path.join(ROOT, "tests", "golden", "scanfold_py_rows.json")))["items"]
+    for it in items:
+        E = np.array([it["energy_list"]])
+        z = sfd.zscores_rows_sff(E, it["r"])[0]
+        assert z == it["zscore"]
+        row = "%d\t%d\t%s\t%s\t%s\t%s\t%s\t%s\t%s\t%s\t%s\n" % (
+            it["start_nucleotide"], it["end_nucleotide"], str(it["temperature"]), str(round(it["energy_list"][0], 2)), str(z),
+            str(round(sff.pvalue_function(it["energy_list"], it["r"]), 2)), str(it["ED"]), it["frag"], it["structure"],
+            it["centroid"], str(sff.get_gc_content(it["frag"])))
+        assert row == it["row"]
+        assert sfd.header_line(it["read_name"]) == it["header"]
+
+
+def test_sff_zscores_rows_equal_per_row_calls_incl_degenerate_rows():
+    rng = np.random.default_rng(3)
+    E = np.round(rng.normal(-25, 4, (2500, 21)), 2).astype(np.float32).astype(np.float64)
+    E[5] = E[5, 0]
+    E[6, 1:] = E[6, 0] + 0.5
+    E[7] = np.arange(21) * 0.05 - 20
+    got = sfd.zscores_rows_sff(E, 20)
+    assert got == [round(sff.zscore_function([float(v) for v in row], 20), 2) for row in E]
+
+
+def test_scan_then_fold_pipeline(emul, oracle, tmp_path, monkeypatch):
+    monkeypatch.setattr(_lib, "_engine", emul)
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.default_rng(4)
+    stem = "GGCGCGGCAC"
+    comp = stem[::-1].translate(str.maketrans("ACGU", "UGCA"))
+    seq = "".join("ACGU"[k] for k in rng.integers(0, 4, 30)) + stem + "GAAA" + comp + "".join("ACGT"[k] for k in rng.integers(0, 4, 26))
+    (tmp_path / "in.fa").write_text(">rec1 x\n" + seq + "\n")
+    assert sfd.main(["in.fa", "-w", "30", "-s", "2", "-r", "6", "--type", "di", "--seed", "3"]) == 0
+    base = "rec1.win_30.stp_2.rnd_6.shfl_di"
+    lines = (tmp_path / (base + ".out")).read_text().split("\n")
+    assert lines[0] == sfd.header_line("rec1").rstrip("\n")
+    tseq = seq.replace("T", "U")
+    rows = [ln.split("\t") for ln in lines[1:-1]]
+    assert len(rows) == (len(seq) - 30) // 2 + 1 and all(len(r) == 11 for r in rows)
+    shuf = np.frombuffer(b"NACGU", dtype=np.uint8)[oracle.shuffle_windows(tseq, 30, 2, 0, len(rows), 6, 1, 3)]
+    E = oracle.mfe_batch(shuf).reshape(len(rows), 7)
+    for k, r in enumerate(rows):
+        frag = tseq[2 * k:2 * k + 30]
+        el = [float(np.float32(v) / np.float32(100)) for v in E[k]]
+        db, e = oracle.mfe(frag)
+        assert r[7] == frag and r[8] == db and r[3] == str(round(el[0], 2)) and r[10] == str(sff.get_gc_content(frag))
+        assert r[4] == str(round(sff.zscore_function(el, 6), 2)) and r[5] == str(round(sff.pvalue_function(el, 6), 2))
+    # the Fold stage ran on ALL windows; its CT file is what scanfold_amd.fold makes of the same table
+    ct = (tmp_path / (base + ".ScanFold.-1.ct")).read_text().split("\n")
+    assert int(ct[0].split("\t")[0]) == len(seq)
+    table = fold.ScanTable("rec1", [int(r[0]) for r in rows], [float(r[3]) for r in rows], [float(r[4]) for r in rows],
+                           [float(r[6]) for r in rows], [r[7] for r in rows], [r[8] for r in rows])
+    tab = fold.Tabulation(table)
+    res = fold.compete(tab, fold.best_partners(tab))
+    paired = sum(1 for ln in ct[1:-1] if int(ln.split()[4]) != 0)
+    assert paired == 2 * fold.structure_string(tab, res, -1.0).count("(")
+    assert os.path.exists(tmp_path / (base + ".ScanFold.final_partners.txt")) and os.path.exists(tmp_path / (base + ".bp"))
+
+
+def test_shape_and_constraint_paths_of_the_combined_driver(emul, oracle, tmp_path, monkeypatch):
+    from scanfold_amd import RNA
+    monkeypatch.setattr(_lib, "_engine", emul)
+    rng = np.random.default_rng(6)
+    seq = "".join("ACGU"[k] for k in rng.integers(0, 4, 50))
+    react = [-999.0] + [float(x) for x in np.round(rng.uniform(0, 2, 50), 2)]
+    react[10] = -999.0
+    rows, table = sfd.scan_rows(seq, 30, 10, 3, "mono", 37, emul, seed=1, reactivities=react, slope=1.8, intercept=-0.6)
+    try:
+        for k, row in enumerate(rows):
+            f = row.rstrip("\n").split("\t")
+            i = 10 * k
+            pe = RNA.deigan_pseudo_energies(react[i + 1:i + 31], 1.8, -0.6, 30)  # the 0-based slice upstream passes
+            oracle.set_constraint(None, pe)
+            db, e = oracle.mfe(seq[i:i + 30])
+            oracle.set_constraint(None, None)
+            o = oracle.pf(seq[i:i + 30])  # centroid / ED from the unconstrained partition function (ScanFold.py:525-527)
+            assert f[8] == db and f[3] == str(round(float(np.float32(e) / np.float32(100)), 2))
+            assert f[9] == o["centroid"] and f[6] == str(round(o["mean_bp_dist"], 2))
+    finally:
+        oracle.set_constraint(None, None)
+    # reactivity file reader (ScanFold.py:218-262): three columns, a gap and an NA
+    p = tmp_path / "r.txt"
+    p.write_text("1\tA\t0.5\n2\tC\tNA\n5\tG\t1.25\n")
+    assert sfd.read_reactivities(str(p)) == [-999.0, 0.5, -999.0, -999.0, -999.0, 1.25]
+    fa = tmp_path / "z.fa"
+    fa.write_text(">z\n" + seq + "\n")
+    with pytest.raises(TypeError):  # --shapeZ: upstream's one-argument sc_add_SHAPE_zarringhalam call is a TypeError
+        sfd.main([str(fa), "-w", "30", "--react", str(p), "--shapeZ"])

@@ -100,10 +100,11 @@ def cpu_baseline(seq, W, step, r, kind, seed, budget_s=15.0):
     oracle.set_params(params.default_params())
     threads, phys, socks = host_cores()
     cores = phys
-    engine = "oracle/sf_oracle.c (the parity checker: O(n^4) outside pass, dense interior-loop search)"
+    engine = "oracle/sf_oracle.c (the parity checker: O(n^4) outside pass, allocations per fold)"
     scan_fn = oracle.scan_windows
     if hasattr(oracle, "twin_available") and oracle.twin_available():
-        engine = "oracle/sf_cpu_twin.c (O(n^3) passes, incremental interior loops)"
+        engine = ("oracle/sf_cpu_twin.c (per-thread workspaces, pair-type matrix, dense interior loops with pre-added "
+                  "mismatch view, vectorisable multiloop split, O(n^3) outside pass)")
         scan_fn = oracle.twin_scan_windows
 
     def run(n_win):
@@ -116,11 +117,43 @@ def cpu_baseline(seq, W, step, r, kind, seed, budget_s=15.0):
     n = int(max(n0, min(20000, n0 * budget_s / max(t0, 1e-6))))
     n = (n // cores) * cores or n0
     t = run(n)
-    return dict(value=n / t, unit="windows/s", cores=cores, kind="port",
+    try:
+        overhead = reference_python_overhead(seq, W, r, windows=4)
+    except Exception as e:  # never let the side measurement break the bench line
+        overhead = {"error": repr(e)}
+    return dict(value=n / t, unit="windows/s", cores=cores, kind="port", reference_python_overhead=overhead,
                 sample="first %d windows of the workload, one OpenMP thread per window on %d threads = the physical "
                        "cores of %d socket(s) (%d hardware threads visible); each window: 1 MFE + traceback, 1 "
                        "partition function, %d MFE folds; %.1f s wall; engine: %s — not ViennaRNA (absent)"
                        % (n, cores, socks, threads, r + 1, t, engine))
+
+
+def _noop(x):
+    return x
+
+
+def reference_python_overhead(seq, W, r, windows=6):
+    """What the reference adds per window on top of its ViennaRNA calls (ScanFold-Scan.py:73-77,256,269-274): r pure
+    Python dinucleotide shuffles in the parent (scanfold_amd.functions.dinuclShuffle is the reference's function draw
+    for draw, tests/test_golden_host.py) and one ProcessPoolExecutor(12) created, fed r+1 items and torn down.
+    Seconds per window, measured on a few windows; lets a reference-shaped figure be reconstructed from a fold rate."""
+    import random
+    from concurrent.futures import ProcessPoolExecutor
+    from scanfold_amd import functions as sff
+    random.seed(1)
+    t0 = time.perf_counter()
+    for w in range(windows):
+        frag = seq[w * 50:w * 50 + W]
+        for _ in range(r):
+            sff.dinuclShuffle(frag)
+    t_shuffle = (time.perf_counter() - t0) / windows
+    t0 = time.perf_counter()
+    for w in range(windows):
+        with ProcessPoolExecutor(12) as ex:
+            list(ex.map(_noop, range(r + 1)))
+    t_pool = (time.perf_counter() - t0) / windows
+    return {"python_dinucl_shuffles_s_per_window": t_shuffle, "process_pool_12_s_per_window": t_pool,
+            "windows_per_s_if_folds_were_free": 1.0 / (t_shuffle + t_pool)}
 
 
 def verify_sample(seq, W, step, r, kind, seed, lo, n_loc, en, db, cen, div, n_check=VERIFY_WINDOWS):

@@ -14,7 +14,7 @@ _lib = None
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith(".c")]
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith(".c")]  # sf_cpu_twin.c is #included by sf_oracle.c
     if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
 
@@ -36,6 +36,8 @@ def lib():
                              ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
         L.sfo_scan_windows.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        L.sfo_twin_scan_windows.argtypes = L.sfo_scan_windows.argtypes
+        L.sfo_twin_mfe_batch.argtypes = L.sfo_mfe_batch.argtypes
         L.sfo_set_constraint.argtypes = [ctypes.c_char_p, ctypes.c_void_p]
         L.sfo_shuffle_windows.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                           ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.c_void_p]
@@ -154,4 +156,34 @@ def shuffle_windows(transcript, W, step, win_begin, n_win, r, kind, seed):
                                    out.ctypes.data)
     if rc:
         raise RuntimeError("sfo_shuffle_windows rc=%d" % rc)
+    return out
+
+
+def twin_available():
+    return hasattr(lib(), "sfo_twin_scan_windows")
+
+
+def twin_scan_windows(rows, n_win, r, nthreads=0):
+    """sf_cpu_twin.c: the same job as scan_windows on the fast CPU engine (bench.py's cpu_baseline)."""
+    arr = np.ascontiguousarray(rows, dtype=np.uint8)
+    W = arr.shape[1]
+    en = np.empty((n_win, r + 1), dtype=np.int32)
+    db = np.zeros((n_win, W + 1), dtype=np.uint8)
+    cen = np.zeros((n_win, W + 1), dtype=np.uint8)
+    ed = np.zeros(n_win)
+    rc = lib().sfo_twin_scan_windows(arr.ctypes.data_as(ctypes.c_char_p), n_win, r, W, en.ctypes.data, db.ctypes.data,
+                                     cen.ctypes.data, ed.ctypes.data, nthreads)
+    if rc:
+        raise RuntimeError("sfo_twin_scan_windows rc=%d" % rc)
+    return dict(energies=en, structure=[bytes(x[:W]).decode() for x in db],
+                centroid=[bytes(x[:W]).decode() for x in cen], ens_div=ed)
+
+
+def twin_mfe_batch(seqs, nthreads=0):
+    arr = np.ascontiguousarray(seqs, dtype=np.uint8)
+    n, W = arr.shape
+    out = np.empty(n, dtype=np.int32)
+    rc = lib().sfo_twin_mfe_batch(arr.ctypes.data_as(ctypes.c_char_p), n, W, out.ctypes.data, nthreads)
+    if rc:
+        raise RuntimeError("sfo_twin_mfe_batch rc=%d" % rc)
     return out

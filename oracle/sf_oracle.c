@@ -990,3 +990,6 @@ int sfo_pf(const char *seq, int n, double *ensemble_dG, double *bpp_out, char *c
   seq_free(&q);
   return 0;
 }
+
+/* =================================== fast CPU twin (baseline only) =================================== */
+#include "sf_cpu_twin.c"

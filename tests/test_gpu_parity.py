@@ -522,3 +522,18 @@ def test_temperature_rescale_on_gpu(gpu_engine, oracle):
     finally:
         oracle.set_params(base)
         gpu_engine.load_params(base)
+
+
+def test_config5_w200_step1_320_consecutive_windows(gpu_engine, oracle):
+    """BASELINE config 5's native-window path — W=200, step=1: in-kernel traceback of the folded-layout MFE kernel and
+    the device-table partition-function kernel — on 320 consecutive windows, every one against the oracle."""
+    seq = synth_transcript(30000, 3)
+    W, lo, n, r = 200, 9000, 320, 3
+    res = gpu_engine.scan(seq, W, 1, lo, n, r, _lib.SHUFFLE_DI, 7)
+    wins = [seq[i:i + W] for i in range(lo, lo + n)]
+    ref = oracle.scan_windows(np.frombuffer("".join(wins).encode(), dtype=np.uint8).reshape(n, W), n, 0)
+    assert (ref["energies"][:, 0] == res["energies"][:, 0]).all()
+    assert ref["structure"] == res["structure"] and ref["centroid"] == res["centroid"]
+    assert np.abs(ref["ens_div"] - res["ens_div"]).max() < PF_TOL
+    rows = ascii_rows(oracle.shuffle_windows(seq, W, 1, lo, n, r, _lib.SHUFFLE_DI, 7))
+    assert (oracle.mfe_batch(rows).reshape(n, r + 1) == res["energies"]).all()

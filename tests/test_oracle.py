@@ -135,3 +135,19 @@ def test_max_bp_span_dp_equals_enumeration(oracle):
                 assert np.abs(r["bpp"] - bpp).max() < 1e-9
     finally:
         oracle.set_max_bp_span(0)
+
+
+def test_cpu_twin_equals_the_oracle(oracle):
+    """oracle/sf_cpu_twin.c (bench.py's CPU baseline engine) against the checker: same energies, structures,
+    centroids; ensemble diversity to 1e-9 — several widths, a window with N, one OpenMP thread and several."""
+    import numpy as np
+    rng = np.random.default_rng(2)
+    for W, n, r, nt in ((16, 30, 4, 1), (30, 40, 5, 2), (61, 12, 3, 1), (120, 6, 8, 2), (200, 2, 2, 1)):
+        rows = np.frombuffer(b"ACGUN", dtype=np.uint8)[rng.choice(5, (n * (r + 1), W), p=[.245, .245, .245, .245, .02])]
+        a = oracle.scan_windows(rows, n, r, nthreads=nt)
+        b = oracle.twin_scan_windows(rows, n, r, nthreads=nt)
+        assert (a["energies"] == b["energies"]).all(), W
+        assert a["structure"] == b["structure"] and a["centroid"] == b["centroid"], W
+        assert np.abs(a["ens_div"] - b["ens_div"]).max() < 1e-9
+    arr = np.frombuffer(b"ACGU", dtype=np.uint8)[rng.integers(0, 4, (200, 90))]
+    assert (oracle.twin_mfe_batch(arr, 2) == oracle.mfe_batch(arr, 2)).all()

@@ -89,6 +89,25 @@ def host_cores():
     return len(cpus), len(phys), max(len(socks), 1)
 
 
+def cpu_quota():
+    """CPUs' worth of time the container may use (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited: the GPU
+    boxes show 256 hardware threads but cap the container at 16 CPUs — more threads than that only take turns."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            return max(1, int(round(int(q) / int(p))))
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            return max(1, int(round(q / p)))
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def cpu_baseline(seq, W, step, r, kind, seed, budget_s=15.0):
     """The CPU engine (oracle/sf_cpu_twin.c when built, else the checker oracle/sf_oracle.c) on a bounded sample of
     the same workload: per window 1 MFE + traceback, 1 partition function and r+1 MFE folds, one OpenMP thread per
@@ -99,7 +118,8 @@ def cpu_baseline(seq, W, step, r, kind, seed, budget_s=15.0):
     oracle.build()
     oracle.set_params(params.default_params())
     threads, phys, socks = host_cores()
-    cores = phys
+    quota = cpu_quota()
+    cores = phys if quota is None else min(phys, quota)
     engine = "oracle/sf_oracle.c (the parity checker: O(n^4) outside pass, allocations per fold)"
     scan_fn = oracle.scan_windows
     if hasattr(oracle, "twin_available") and oracle.twin_available():
@@ -122,10 +142,12 @@ def cpu_baseline(seq, W, step, r, kind, seed, budget_s=15.0):
     except Exception as e:  # never let the side measurement break the bench line
         overhead = {"error": repr(e)}
     return dict(value=n / t, unit="windows/s", cores=cores, kind="port", reference_python_overhead=overhead,
-                sample="first %d windows of the workload, one OpenMP thread per window on %d threads = the physical "
-                       "cores of %d socket(s) (%d hardware threads visible); each window: 1 MFE + traceback, 1 "
+                host={"hardware_threads": threads, "physical_cores": phys, "sockets": socks, "cgroup_cpu_quota": quota},
+                sample="first %d windows of the workload, one OpenMP thread per window on %d threads (%s; the host has "
+                       "%d physical cores in %d socket(s), %d hardware threads); each window: 1 MFE + traceback, 1 "
                        "partition function, %d MFE folds; %.1f s wall; engine: %s — not ViennaRNA (absent)"
-                       % (n, cores, socks, threads, r + 1, t, engine))
+                       % (n, cores, "the container's CPU quota" if quota is not None and quota < phys else
+                          "one per physical core", phys, socks, threads, r + 1, t, engine))
 
 
 def _noop(x):

@@ -603,7 +603,9 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
     X.CI[rbd] = SF_INF16; sf_stw(X.BN + 2 * rbd, sf_pk(SF_INF16, SF_INF16));
   }
   // the scratch (row i, column j: the exterior sweep reads rows coalesced) takes c + ExtLoop, the only form the
-  // sweep needs; the traceback (native windows only) subtracts the term again (sf_fast_c)
+  // sweep needs; the traceback (native windows only) subtracts the term again (sf_fast_c).  (Storing only the cells
+  // that can pair — 3 of 8 — and masking the rest in the sweeps was measured: -5 % speed, and MORE memory traffic,
+  // 16 kB against 7.5 kB written per fold: partially written lines are fetched first.  profiles/r02/mfe_scratch_traffic.txt)
   X.cg[SF_CGIDX(i, j)] = (int16_t)cx;
   // fML[i,j]: the two neighbours on diagonal d-1 are final only for the even-diagonal group, which gets their
   // minimum (+MLbase) in fnb from its own fix-up of the previous step (see the kernel)
@@ -973,6 +975,56 @@ __device__ __forceinline__ void sf_fast_exterior(const SfFastCtx &X, const int W
   }
 }
 
+// Deferred exterior sweep (W <= 128 only).  A fold whose structure is not wanted does not run its exterior sweep at
+// its own end — one wave working for ~50 k cycles while the fold's other three wait at the next barrier, 8 % of a
+// fold's residency — but hands its c + ExtLoop scratch (the workgroup owns two, used alternately) to the NEXT fold:
+// the helper wave of the odd diagonal group sweeps SF_DEFER_ROWS rows of it in every step of the long-diagonal
+// phase, in the slack it has there (it only computes the special / bulge / 1xn minima of its step).  The row loads
+// are issued before that work and consumed after it.  State: the two column minima, f5 of the previous row.
+#ifndef SF_DEFER
+#define SF_DEFER 1
+#endif
+struct SfDeferred {
+  int P0, P1, f5p;  // lane l: running minima of columns l+1 and l+65; f5[row-1]
+  int row;          // next row to sweep (1-based); 0 = nothing pending
+  int seq, over;    // the pending fold's index and its int16-overflow flag
+};
+__device__ __forceinline__ void sf_defer_load(const int16_t *cgp, const int W, const int lane, const int i, int &c0, int &c1) {
+  const int j0 = lane + 1, j1 = lane + 65;
+  c0 = (i <= W - SFD_TURN - 1 && j0 <= W && i + SFD_TURN + 1 <= j0) ? (int)cgp[SF_CGIDX(i, j0)] : SF_INF16;
+  c1 = (i <= W - SFD_TURN - 1 && j1 <= W && i + SFD_TURN + 1 <= j1) ? (int)cgp[SF_CGIDX(i, j1)] : SF_INF16;
+}
+__device__ __forceinline__ int sf_defer_colmin(const SfDeferred &Q, const int jf) {  // P of column jf from its lane
+  const int l = (jf - 1) & 63;
+  const int v0 = SF_LANE_READ(Q.P0, l), v1 = SF_LANE_READ(Q.P1, l);
+  return (jf - 1) >> 6 ? v1 : v0;
+}
+__device__ __forceinline__ void sf_defer_row(SfDeferred &Q, const int W, const int i, const int c0, const int c1) {
+  if (i > W - SFD_TURN - 1) return;
+  if (i >= 2) Q.f5p = sfd_min(Q.f5p, sf_defer_colmin(Q, i - 1));
+  Q.P0 = sfd_min(Q.P0, Q.f5p + c0);
+  Q.P1 = sfd_min(Q.P1, Q.f5p + c1);
+}
+// rest of the sweep (if any), the last columns, the result
+__device__ __forceinline__ void sf_defer_finish(SfDeferred &Q, const int16_t *cgp, const int W, const int lane,
+                                                int32_t *__restrict__ out, int *__restrict__ ovf_cnt,
+                                                int *__restrict__ ovf_list) {
+  for (int i = Q.row; i <= W - SFD_TURN - 1; i++) {
+    int c0, c1;
+    sf_defer_load(cgp, W, lane, i, c0, c1);
+    sf_defer_row(Q, W, i, c0, c1);
+  }
+  for (int jf = sfd_max(W - SFD_TURN - 1, 1); jf <= W; jf++) Q.f5p = sfd_min(Q.f5p, sf_defer_colmin(Q, jf));
+  if (lane == 0) {
+    out[Q.seq] = Q.f5p;
+    if (Q.over || Q.f5p < SF_FAST_OVF) {
+      const int k = atomicAdd(ovf_cnt, 1);
+      ovf_list[k] = Q.seq;
+    }
+  }
+  Q.row = 0;
+}
+
 template <int NG, int WT>
 __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_kernel(const uint8_t *__restrict__ seqs, int n, int Wrt,
                                                              const SfDevParams *__restrict__ D,
@@ -1013,7 +1065,8 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
   int16_t *tExt = (int16_t *)(smem + Lo.off_ci + (((W + 1) * 4 + 3) & ~3));
 
   const int tid = threadIdx.x;
-  X.cg = cg_all + (size_t)blockIdx.x * SF_CG_ENTRIES(W);  // c by (row i, column j), triangular
+  int16_t *const cg_pair = cg_all + (size_t)blockIdx.x * 2 * SF_CG_ENTRIES(W);  // two scratch tables, used alternately
+  X.cg = cg_pair;                                                                // c + ExtLoop by (row i, column j), triangular
   // parameter tables -> LDS, once per workgroup
   for (int x = tid; x < 175; x += NT) {
     tab[x] = F->mm23[x];
@@ -1045,8 +1098,20 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
   // first even diagonal from which the cells of both groups lie in the lanes tg < 64 (W >= 64: OFF >= 0, no wrap)
   const int split_d0 = (NG == 128 && W >= 64 && SF_FAST_SPLIT) ? ((sfd_max(sfd_max(SFD_MAXLOOP + 6, 2 * (OFF - 1)), 2 * (W - OFF - 63)) + 1) & ~1) : 1 << 30;
 
+  // deferred exterior sweep: wave 3 (the helper of the odd group) works on the previous fold's scratch
+  constexpr bool DEFER = SF_DEFER && (NG == 128);
+  const bool sweeper = DEFER && SF_WAVE_UNIFORM(tid >> 6) == 3;
+  const int n_split_steps = split_d0 < W ? (W - split_d0 + 1) / 2 : 0;
+  const int defer_rows = n_split_steps > 0 ? (W - SFD_TURN - 1 + n_split_steps - 1) / n_split_steps : 0;  // rows per step
+  const bool defer_on = DEFER && n_split_steps >= 8 && defer_rows <= 4;
+  SfDeferred Q;
+  Q.P0 = Q.P1 = SF_FAST_BIG * 2; Q.f5p = 0; Q.row = 0; Q.seq = -1; Q.over = 0;
+  int cur_buf = 0;
+  const int16_t *pend_cg = cg_pair;
+
   for (int seq = blockIdx.x; seq < n; seq += gridDim.x) {
     const uint8_t *src = seqs + (size_t)seq * W;
+    X.cg = cg_pair + (size_t)cur_buf * SF_CG_ENTRIES(W);
     __syncthreads();
     for (int x = tid; x < W; x += NT) S[x + 1] = sf_encode_nt(src[x]);
     if (tid == 0) { S[0] = 0; S[W + 1] = 0; flag[0] = 0; }
@@ -1093,6 +1158,14 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
 #ifdef SF_STAMP
       const unsigned long long t0 = SF_T();
 #endif
+      // deferred sweep of the previous fold: this step's rows are requested now, used after the wave's own work
+      int dc[4][2];
+      const bool sweep_now = defer_on && sweeper && split && Q.row > 0;
+      if (sweep_now) {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          if (k < defer_rows) sf_defer_load(pend_cg, W, tid & 63, Q.row + k, dc[k][0], dc[k][1]);
+      }
 #ifdef SF_ABL_CELL
       if (0) {
 #else
@@ -1106,6 +1179,12 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
           sf_fast_cell<false, WT, SF_SEC_HELP, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev);
           if (valid) X.BN[2 * (slotd * (W - 4) + i - 1) + 1] = (int16_t)sfd_min(eh, 32000);
         }
+      }
+      if (sweep_now) {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          if (k < defer_rows) sf_defer_row(Q, W, Q.row + k, dc[k][0], dc[k][1]);
+        Q.row += defer_rows;
       }
 #ifdef SF_STAMP
       const unsigned long long tA = SF_T();
@@ -1167,6 +1246,19 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
     const unsigned long long tf0 = SF_T();
 #endif
     if (ovf) flag[0] = 1;
+    // the previous fold's deferred sweep ends here at the latest
+    if (sweeper && Q.row > 0) sf_defer_finish(Q, pend_cg, W, tid & 63, out, ovf_cnt, ovf_list);
+    const bool want_trace_now = db_out && (seq % trace_stride) == 0;
+    const bool last_fold = seq + (int)gridDim.x >= n;
+    if (defer_on && !want_trace_now && !last_fold) {
+      // hand this fold's scratch to the next fold's helper wave
+      __syncthreads();  // every thread's overflow flag and scratch stores are in
+      if (sweeper) {
+        Q.P0 = Q.P1 = SF_FAST_BIG * 2; Q.f5p = 0; Q.row = 1; Q.seq = seq; Q.over = flag[0];
+      }
+      pend_cg = X.cg;
+      cur_buf ^= 1;
+    } else {
     for (int x = tid; x < 200; x += NT) tExt[x] = F->mmExt[x];
     __syncthreads();
     // (the scratch already holds c + ExtLoop: the sweep is one add and one min per cell; the mismatchExt table
@@ -1179,6 +1271,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
       sf_fast_exterior<NG / 64>(X, W, tid, seq, f5s, tExt, etab, flag, (int16_t *)(smem + Lo.off_cb),
                       (char *)(smem + Lo.off_cb + ((3 * (W + 8) * 2 + 3) & ~3)), out, ovf_cnt, ovf_list, trace_stride,
                       db_out, status);
+    }
 #ifdef SF_STAMP
     if (blockIdx.x == 0 && (tid & 63) == 0) sf_stamp_acc[tid >> 6][4] += SF_T() - tf0;
 #endif
@@ -1214,7 +1307,7 @@ static inline void sf_fast_geometry(int W, int n_cu, int n, int *grid, int *thre
   *grid = (int)gsz;
   *threads = nt;
   *lds = (size_t)L.total;
-  *scratch = (size_t)gsz * SF_CG_ENTRIES(W) * sizeof(int16_t);
+  *scratch = (size_t)gsz * 2 * SF_CG_ENTRIES(W) * sizeof(int16_t);  // two per workgroup (deferred exterior sweep)
 }
 
 // W = 120 is ScanFold's default window (ScanFold-Scan.py:37) and W = 200 is BASELINE config 5: they get

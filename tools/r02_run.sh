@@ -26,8 +26,15 @@ def pmc_sum(pattern, kernel, min_grid=0, per=None):
             if kernel in r["Kernel_Name"] and int(r["Grid_Size"]) >= min_grid:
                 acc[r["Counter_Name"]] = acc.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
     return acc
-fetch = pmc_sum(O + "/pmc_FETCH_SIZE/*/*counter_collection.csv", "sf_mfe_fast_kernel")
-write = pmc_sum(O + "/pmc_WRITE_SIZE/*/*counter_collection.csv", "sf_mfe_fast_kernel")
+def pmc_max(pattern, kernel):  # the largest dispatch = the one full cfg3 launch of the timed step (the e2e leg launches chunks)
+    best = {}
+    for f in glob.glob(pattern):
+        for r in csv.DictReader(open(f)):
+            if kernel in r["Kernel_Name"]:
+                best[r["Counter_Name"]] = max(best.get(r["Counter_Name"], 0.0), float(r["Counter_Value"]))
+    return best
+fetch = pmc_max(O + "/pmc_FETCH_SIZE/*/*counter_collection.csv", "sf_mfe_fast_kernel")
+write = pmc_max(O + "/pmc_WRITE_SIZE/*/*counter_collection.csv", "sf_mfe_fast_kernel")
 sq = {}
 for k in (1, 2, 3):
     sq.update(pmc_sum(O + "/sq_%d/*/*counter_collection.csv" % k, "sf_mfe_fast_kernel", 1024 * 128))

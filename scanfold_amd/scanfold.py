@@ -8,8 +8,9 @@ Restates the scan section of /root/reference/ScanFold.py (:420-757) — the Scan
   --constraints: constrained native fold; --react: Deigan SHAPE term for the MFE only   ScanFold.py:508-544
 and then feeds the windows straight into the Fold stage (scanfold_amd.fold; ScanFold.py:564-677,1036-1453) without a
 TSV round trip.  Output: `<name>.win_W.stp_S.rnd_R.shfl_T.out` (the scan table, ScanFold.py:381,685) and the Fold
-stage's files with the prefix `<that>.ScanFold.` — ScanFold.py's per-record directories, IGV wig / gff3 exports, global
-refold and motif extraction are not reproduced.
+stage's files with the prefix `<that>.ScanFold.`, then the dot-bracket files (makedbn) and the motif extraction /
+refolds of ScanFold.py:1582-1776 (scanfold_amd.motifs: `<that>.ExtractedStructures.gff3`, `<that>_motif_<n>.dbn/.ct`).
+ScanFold.py's per-record directories, IGV wig exports and the full-length global refold are not reproduced.
 """
 import argparse
 import os
@@ -21,6 +22,8 @@ import numpy as np
 from . import _lib, fold as foldmod
 from . import functions as sff
 from . import scan as scanmod
+from . import motifs as motifmod
+from . import writers
 
 
 def header_line(read_name):
@@ -160,6 +163,7 @@ def build_parser():
     p.add_argument('--constraints', type=str, help='optional | input constraint file')
     p.add_argument('--span', type=int, help='Max bp span')
     p.add_argument('--dont_fold', action='store_true', help='scan only')
+    p.add_argument('--dont_extract', action='store_true', help='no motif extraction / refolds after the Fold stage')
     p.add_argument('--seed', type=int, default=0)
     p.add_argument('--params', type=str, default=None)
     p.add_argument('--constraint-unbalanced', choices=("error", "ignore"), default="error")
@@ -205,6 +209,14 @@ def main(argv=None):
             table.id = read_name
             # ScanFold.py tabulates every window (its inline loop has no dropped first row, unlike ScanFold-Fold.py)
             foldmod.fold(table, outname + ".ScanFold.", filt=int(args.f), bp_path=outname + ".bp")
+            for tag, label in (("no_filter", "NoFilter"), ("-1", "Zavg_-1"), ("-2", "Zavg_-2")):
+                writers.makedbn(outname + ".ScanFold." + tag, label)  # ScanFold.py:1487-1489
+            if not args.dont_extract:
+                with open(outname + ".ScanFold.-2.dbn") as f:
+                    line = f.readlines()[2]
+                found = motifmod.extract_structures(line, seq)
+                motifmod.refold_motifs(read_name, found, args.type, outname + ".ExtractedStructures.gff3",
+                                       folder=motifmod.EngineFolder(args.t, args.algo), file_prefix=outname)
     return 0
 
 

@@ -10,7 +10,8 @@ makedbn(ctfile, name)                       :67-138    same signature: <ctfile>.
 The per-nucleotide dictionaries of NucZscore objects the reference passes around are plain strings / lengths here.
 Outputs are pinned byte for byte by tests/golden/writers.json (the reference's functions run on the same inputs by
 tests/golden/make_golden_writers.py).  The CT / .bp / log writers of the Fold stage live in scanfold_amd/fold.py.
-Not reproduced: write_dp (competition-free mode), gff3 motif extraction and the varna / PS plots of ScanFold.py:1484-1779.
+Motif extraction, the motif refolds and their gff3 / dbn2ct files: scanfold_amd/motifs.py.
+Not reproduced: write_dp (competition-free mode) and the varna / PS plots of ScanFold.py:1484-1779.
 """
 
 

@@ -537,3 +537,40 @@ def test_config5_w200_step1_320_consecutive_windows(gpu_engine, oracle):
     assert np.abs(ref["ens_div"] - res["ens_div"]).max() < PF_TOL
     rows = ascii_rows(oracle.shuffle_windows(seq, W, 1, lo, n, r, _lib.SHUFFLE_DI, 7))
     assert (oracle.mfe_batch(rows).reshape(n, r + 1) == res["energies"]).all()
+
+
+def test_motif_refolds_on_gpu(gpu_engine, oracle, tmp_path, monkeypatch):
+    """ScanFold.py:1726-1776 on the engine: constrained MFE / ensemble diversity of each extracted motif and the
+    z-score of its unconstrained energy against host-shuffled copies, every number re-derived with the oracle."""
+    import random
+    from scanfold_amd import motifs, functions as sff
+    monkeypatch.setattr(_lib, "_engine", gpu_engine)
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.default_rng(12)
+    seq, line = "", ""
+    for k in range(6):
+        stem = "".join("ACGU"[v] for v in rng.integers(0, 4, 5 + k)) + "GC"
+        comp = stem[::-1].translate(str.maketrans("ACGU", "UGCA"))
+        loop = "".join("ACGU"[v] for v in rng.integers(0, 4, 4 + 3 * k))
+        gap = "".join("ACGU"[v] for v in rng.integers(0, 4, 3 + k))
+        seq += gap + stem + loop + comp
+        line += "." * len(gap) + "(" * len(stem) + "." * len(loop) + ")" * len(stem)
+    ms = motifs.extract_structures(line + ".\n", seq + "A")
+    assert len(ms) == 6
+    random.seed(5)
+    recs = motifs.refold_motifs("rec", ms, "di", "x.gff3")
+    random.seed(5)
+    try:
+        for m, rec in zip(ms, recs):
+            oracle.set_constraint(m.structure, None)
+            db, e = oracle.mfe(m.sequence)
+            assert (rec["structure"], rec["mfe"]) == (db, round(float(np.float32(e) / np.float32(100)), 2))
+            assert rec["ed"] == round(oracle.pf(m.sequence)["mean_bp_dist"], 2)
+            oracle.set_constraint(None, None)
+            seqlist = [m.sequence] + sff.scramble(m.sequence, 100, "di")
+            el = [float(np.float32(v) / np.float32(100)) for v in oracle.mfe_batch(seqlist)]
+            assert rec["zscore"] == round(sff.zscore_function(el, 100), 2)
+            assert rec["pvalue"] == round(sff.pvalue_function(el, 100), 2)
+    finally:
+        oracle.set_constraint(None, None)
+    assert len(open("x.gff3").read().split("\n")) == 7

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from scanfold_amd import _lib, fold, functions as sff, params
+from scanfold_amd import motifs, _lib, fold, functions as sff, params
 from scanfold_amd import scanfold as sfd
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -78,6 +78,27 @@ def test_scan_then_fold_pipeline(emul, oracle, tmp_path, monkeypatch):
     paired = sum(1 for ln in ct[1:-1] if int(ln.split()[4]) != 0)
     assert paired == 2 * fold.structure_string(tab, res, -1.0).count("(")
     assert os.path.exists(tmp_path / (base + ".ScanFold.final_partners.txt")) and os.path.exists(tmp_path / (base + ".bp"))
+    # dot-bracket files + motif extraction / refolds (ScanFold.py:1487-1489, 1582-1776): every gff3 line is the
+    # constrained refold of a top-level helix of the -2 line, checked against the oracle
+    dbn = (tmp_path / (base + ".ScanFold.-2.dbn")).read_text().split("\n")
+    assert dbn[0] == ">Zavg_-2" and dbn[1] == tseq and len(dbn[2]) == len(seq)
+    assert dbn[2] == fold.structure_string(tab, res, -2.0)
+    gff = (tmp_path / (base + ".ExtractedStructures.gff3")).read_text().split("\n")[:-1]
+    ms = motifs.extract_structures(dbn[2] + "\n", tseq, verbose=False)
+    assert len(gff) == len(ms) >= 1  # the planted hairpin
+    try:
+        for num, (ln, m) in enumerate(zip(gff, ms), start=1):
+            f = ln.split("\t")
+            att = dict(kv.split("=", 1) for kv in f[8].split(";")[1:])
+            assert f[0] == "rec1" and (int(f[3]), int(f[4])) == (m.i + 1, m.j + 1) and att["sequence"] == tseq[m.i:m.j + 1]
+            oracle.set_constraint(m.structure, None)
+            db, e = oracle.mfe(m.sequence)
+            assert att["refoldedMFE"] == db and att["MFE(kcal/mol)"] == str(round(float(np.float32(e) / np.float32(100)), 2))
+            assert att["ED"] == str(round(oracle.pf(m.sequence)["mean_bp_dist"], 2))
+            assert (tmp_path / (base + "_motif_%d.dbn" % num)).read_text().split("\n")[2] == db
+            assert os.path.exists(tmp_path / (base + "_motif_%d.ct" % num))
+    finally:
+        oracle.set_constraint(None, None)
 
 
 def test_shape_and_constraint_paths_of_the_combined_driver(emul, oracle, tmp_path, monkeypatch):

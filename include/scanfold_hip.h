@@ -39,7 +39,8 @@ typedef enum sf_status {
   SF_ERR_HIP = -6,          /* a HIP runtime call failed; sf_last_hip_error() has the text */
   SF_ERR_NO_DEVICE = -7,    /* no usable GPU */
   SF_ERR_INTERNAL = -8,     /* a traceback found no decomposition (would indicate a kernel bug) */
-  SF_ERR_CONSTRAINT = -9    /* unbalanced brackets in a window's constraint string (ViennaRNA aborts there) */
+  SF_ERR_CONSTRAINT = -9,   /* unbalanced brackets in a window's constraint string (ViennaRNA aborts there) */
+  SF_ERR_TABLE = -10        /* sf_tabulate_pairs: an unbalanced structure string, or window starts not ascending */
 } sf_status;
 
 #define SF_MAX_W 400 /* longest window the kernels accept */
@@ -121,6 +122,24 @@ int sf_scan_dev(const uint8_t *d_transcript, int L, int W, int step, int win_beg
  * any traceback since the last report found no decomposition of a cell (never seen; it would be a kernel bug), else
  * SF_OK, and clears the flag.  The host-pointer calls (sf_scan, sf_mfe_trace_batch) report it themselves. */
 int sf_last_status(void);
+
+/* Base-pair tabulation of a scan table — the first half of the Fold stage.  Replaces the window loop that appends each
+ * window's (z-score, MFE, ED) to the list of every (nucleotide, partner) pair its structure holds, and the np.sum over
+ * every such list (ScanFold-Fold.py:583-682,704-760; ScanFold.py:564-677,1080-1180).
+ *   structures   n_win rows of dot-bracket characters ('(' ')' anything else = unpaired), row_stride bytes apart
+ *                (W + 1 for the rows sf_scan / sf_scan_dev wrote); a DEVICE pointer if structures_on_device != 0
+ *                (the table sf_scan_dev left resident), else a host pointer
+ *   starts       coordinate of each window's first nucleotide, strictly ascending (host)
+ *   z, mfe, ed   the window metrics as the scan table prints them (host, n_win doubles each)
+ * A "group" is one (nucleotide k, partner j) pair; j == k stands for "k unpaired in that window".  Groups come out
+ * ordered by k, and inside one k by the first window that holds them (the reference's dict insertion order).
+ * The sums add the supporting windows' values in window order with numpy's pairwise scheme: bit-equal to np.sum.
+ * sf_tabulate_pairs leaves the result on the device and reports its size; sf_tabulate_fetch copies it out
+ * (n_groups entries per array; any pointer may be NULL).  Needs sf_init only (no energy parameters). */
+int sf_tabulate_pairs(const char *structures, int row_stride, int structures_on_device, int n_win, int W,
+                      const int32_t *starts, const double *z, const double *mfe, const double *ed, int64_t *n_groups);
+int sf_tabulate_fetch(int32_t *group_k, int32_t *group_j, int32_t *group_windows, int32_t *group_first_window,
+                      double *group_sum_z, double *group_sum_mfe, double *group_sum_ed);
 
 /* Maximum base-pair span of the folding model.  Replaces md.max_bp_span = args.span (ScanFold.py:214-215; the
  * Scan stage script has no such flag): base pairs (i, j) with j - i + 1 > span do not exist, in the MFE fill, the

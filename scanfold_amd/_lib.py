@@ -45,6 +45,10 @@ _EXPORTS = {
                                    ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint, ctypes.c_void_p,
                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                    ctypes.c_void_p]),
+    "sf_tabulate_pairs": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                         ctypes.POINTER(ctypes.c_int64)]),
+    "sf_tabulate_fetch": (ctypes.c_int, [ctypes.c_void_p] * 7),
     "sf_last_status": (ctypes.c_int, []),
     "sf_prof_stop": (ctypes.c_int, []),
     "sf_set_kernel_mode": (ctypes.c_int, [ctypes.c_int]),
@@ -241,6 +245,35 @@ class Engine:
             return dict(energies=en, structure=db, centroid=cen, ens_div=div, ens_dG=dG)
         return dict(energies=en, structure=[bytes(x[:W]).decode() for x in db],
                     centroid=[bytes(x[:W]).decode() for x in cen], ens_div=div, ens_dG=dG)
+
+    def tabulate_pairs(self, structures, starts, z, mfe, ed, W=None, row_stride=None, on_device=False):
+        """Base-pair tabulation of a scan table (ScanFold-Fold.py:583-682,704-760) -> dict of per-group arrays
+        k, j (j == k: unpaired), windows, first_window, sum_z, sum_mfe, sum_ed, ordered by k then first window.
+        structures: list of W-char str, a uint8 array (n, >= W) (e.g. the raw (n, W+1) table of scan(raw=True)), or —
+        with on_device=True, W and row_stride given — the device pointer of the table sf_scan_dev wrote."""
+        starts = np.ascontiguousarray(starts, dtype=np.int32)
+        n = len(starts)
+        z, mfe, ed = (np.ascontiguousarray(v, dtype=np.float64) for v in (z, mfe, ed))
+        if not (len(z) == len(mfe) == len(ed) == n):
+            raise ValueError("one z-score, MFE and ED per window")
+        if on_device:
+            ptr, keep = int(structures), None
+        else:
+            keep = seqs_to_array(structures) if not isinstance(structures, np.ndarray) else np.ascontiguousarray(structures, dtype=np.uint8)
+            if keep.ndim != 2 or keep.shape[0] != n:
+                raise ValueError("one structure row per window")
+            row_stride = keep.shape[1]
+            W = row_stride if W is None else W
+            ptr = keep.ctypes.data
+        ng = ctypes.c_int64(0)
+        self._check(self.lib.sf_tabulate_pairs(ptr, int(row_stride), 1 if on_device else 0, n, int(W), starts.ctypes.data,
+                                               z.ctypes.data, mfe.ctypes.data, ed.ctypes.data, ctypes.byref(ng)))
+        g = int(ng.value)
+        out = dict(k=np.empty(g, np.int32), j=np.empty(g, np.int32), windows=np.empty(g, np.int32),
+                   first_window=np.empty(g, np.int32), sum_z=np.empty(g), sum_mfe=np.empty(g), sum_ed=np.empty(g))
+        self._check(self.lib.sf_tabulate_fetch(*(out[key].ctypes.data for key in
+                                                 ("k", "j", "windows", "first_window", "sum_z", "sum_mfe", "sum_ed"))))
+        return out
 
     # -- device-buffer entry points (pointers are ints, e.g. torch.Tensor.data_ptr(); stream 0 = library stream) --
     def mfe_batch_dev(self, d_seqs, n, W, d_out, stream=0):

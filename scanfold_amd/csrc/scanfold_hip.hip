@@ -20,6 +20,7 @@
 #include "sf_pf_fast.hip.h"
 #include "sf_pf_lds.hip.h"
 #include "sf_shuffle.hip.h"
+#include "sf_tabulate.hip.h"
 
 namespace {
 
@@ -40,6 +41,8 @@ struct Ctx {
   SfFastParams *dF = nullptr;
   double temperature = 37.0;
   DevBuf full_scratch, pf_scratch, pf_share, fast_scratch, seqs, energies, db, cen, dbl, status, transcript, ovf, cons, sc;
+  DevBuf tab_in, tab_partner, tab_counts, tab_out;  // sf_tabulate_pairs
+  int64_t tab_groups = -1;
   std::string last_hip_error;
   // profiling of the dominant kernel
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;  // recorded only while profiling is on (sf_prof_reset)
@@ -337,6 +340,7 @@ int read_status(hipStream_t st, bool whole_device) {
   HIPCHK(hipMemcpy(&v, g.status.p, sizeof(int), hipMemcpyDeviceToHost));
   if (v) HIPCHK(hipMemset(g.status.p, 0, sizeof(int)));
   if (v & 2) return SF_ERR_CONSTRAINT;  // unbalanced brackets in a window's constraint string
+  if (v & (SF_TAB_ST_UNBALANCED | SF_TAB_ST_TOO_MANY)) return SF_ERR_TABLE;
   return v ? SF_ERR_INTERNAL : SF_OK;
 }
 
@@ -355,6 +359,7 @@ const char *sf_strerror(int status) {
     case SF_ERR_HIP: return "HIP runtime error (see sf_last_hip_error)";
     case SF_ERR_NO_DEVICE: return "no usable GPU device";
     case SF_ERR_INTERNAL: return "internal error: traceback found no decomposition";
+    case SF_ERR_TABLE: return "scan table: unbalanced structure string, or window starts not ascending";
     case SF_ERR_CONSTRAINT: return "unbalanced brackets in a window's constraint string";
     default: return "unknown status";
   }
@@ -403,7 +408,8 @@ int sf_shutdown(void) {
   if (!g.init) return SF_OK;
   hipDeviceSynchronize();
   DevBuf *bufs[] = {&g.full_scratch, &g.pf_scratch, &g.pf_share, &g.fast_scratch, &g.seqs, &g.energies, &g.db, &g.cen,
-                    &g.dbl, &g.status, &g.transcript, &g.ovf, &g.cons, &g.sc};
+                    &g.dbl, &g.status, &g.transcript, &g.ovf, &g.cons, &g.sc, &g.tab_in, &g.tab_partner, &g.tab_counts,
+                    &g.tab_out};
   for (DevBuf *b : bufs) {
     if (b->p) hipFree(b->p);
     b->p = nullptr;
@@ -659,6 +665,107 @@ int sf_scan(const uint8_t *transcript, int L, int W, int step, int win_begin, in
     if (ens_dG) HIPCHK(hipMemcpyAsync(ens_dG, d_dG, n_win * sizeof(double), hipMemcpyDeviceToHost, g.stream));
   }
   return read_status(g.stream, false);
+}
+
+// output arrays of sf_tabulate_pairs inside g.tab_out: four int32 arrays, then three double arrays, n entries each
+struct TabOut {
+  int32_t *gk, *gj, *gcount, *gfirst;
+  double *sz, *sm, *se;
+};
+static TabOut tab_out_views(int64_t n) {
+  TabOut o;
+  char *p = (char *)g.tab_out.p;
+  const size_t n8 = ((size_t)n + 1) & ~(size_t)1;  // keeps the doubles 8-byte aligned
+  o.gk = (int32_t *)p;
+  o.gj = o.gk + n8;
+  o.gcount = o.gj + n8;
+  o.gfirst = o.gcount + n8;
+  o.sz = (double *)(o.gfirst + n8);
+  o.sm = o.sz + n8;
+  o.se = o.sm + n8;
+  return o;
+}
+
+int sf_tabulate_pairs(const char *structures, int row_stride, int structures_on_device, int n_win, int W,
+                      const int32_t *starts, const double *z, const double *mfe, const double *ed, int64_t *n_groups) {
+  if (!g.init) return SF_ERR_NOT_INIT;
+  g.tab_groups = -1;
+  if (n_win < 1 || W < 1 || W > SF_MAX_W || row_stride < W || !structures || !starts || !z || !mfe || !ed || !n_groups)
+    return SF_ERR_BAD_ARG;
+  for (int w = 1; w < n_win; w++)
+    if (starts[w] <= starts[w - 1]) return SF_ERR_TABLE;
+  const int64_t span = (int64_t)starts[n_win - 1] + W - starts[0];  // coordinates starts[0] .. last start + W - 1
+  if (span > 0x7fffff00 || (int64_t)n_win * W > 0x7fffff00) return SF_ERR_BAD_ARG;
+  const int lo = starts[0], n_coords = (int)span;
+  hipStream_t st = g.stream;
+  // inputs: [starts int32 n (padded to 8 bytes)] [z] [mfe] [ed] [structures, host case]
+  const size_t off_z = (((size_t)n_win * 4) + 7) & ~(size_t)7;
+  const size_t off_s = off_z + 3 * (size_t)n_win * 8;
+  int rc = ensure(g.tab_in, off_s + (structures_on_device ? 0 : (size_t)n_win * row_stride));
+  if (rc) return rc;
+  char *in = (char *)g.tab_in.p;
+  HIPCHK(hipMemcpyAsync(in, starts, (size_t)n_win * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(in + off_z, z, (size_t)n_win * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(in + off_z + (size_t)n_win * 8, mfe, (size_t)n_win * 8, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(in + off_z + 2 * (size_t)n_win * 8, ed, (size_t)n_win * 8, hipMemcpyHostToDevice, st));
+  const char *d_structs = structures;
+  if (!structures_on_device) {
+    HIPCHK(hipMemcpyAsync(in + off_s, structures, (size_t)n_win * row_stride, hipMemcpyHostToDevice, st));
+    d_structs = in + off_s;
+  } else {
+    HIPCHK(hipDeviceSynchronize());  // the table may have been written on the caller's stream
+  }
+  const int32_t *d_starts = (const int32_t *)in;
+  const double *d_z = (const double *)(in + off_z), *d_m = d_z + n_win, *d_e = d_m + n_win;
+  rc = ensure(g.tab_partner, (size_t)n_win * W * sizeof(int16_t));
+  if (rc) return rc;
+  rc = ensure(g.tab_counts, ((size_t)n_coords + 1) * sizeof(int32_t));
+  if (rc) return rc;
+  int16_t *d_partner = (int16_t *)g.tab_partner.p;
+  int32_t *d_counts = (int32_t *)g.tab_counts.p;
+  int *d_status = (int *)g.status.p;
+  SF_LAUNCH(sf_tab_partner_kernel, (n_win + 63) / 64, 64, (size_t)64 * (W / 2 + 1) * sizeof(int16_t), st, d_structs,
+            row_stride, n_win, W, d_partner, d_status);
+  SF_LAUNCH(sf_tab_groups_kernel<false>, n_coords, 64, 0, st, (const int16_t *)d_partner, d_starts, n_win, W, lo, d_counts,
+            d_z, d_m, d_e, (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr,
+            (double *)nullptr, (double *)nullptr, (double *)nullptr, d_status);
+  SF_LAUNCH(sf_tab_scan_kernel, 1, 256, 0, st, d_counts, n_coords);
+  HIPCHK(hipGetLastError());
+  int32_t total = 0;
+  HIPCHK(hipMemcpyAsync(&total, d_counts + n_coords, sizeof total, hipMemcpyDeviceToHost, st));
+  rc = read_status(st, false);
+  if (rc) return rc;
+  const size_t n8 = ((size_t)total + 1) & ~(size_t)1;
+  rc = ensure(g.tab_out, n8 * (4 * sizeof(int32_t) + 3 * sizeof(double)) + 16);
+  if (rc) return rc;
+  TabOut o = tab_out_views(total);
+  SF_LAUNCH(sf_tab_groups_kernel<true>, n_coords, 64, 0, st, (const int16_t *)d_partner, d_starts, n_win, W, lo, d_counts,
+            d_z, d_m, d_e, o.gk, o.gj, o.gcount, o.gfirst, o.sz, o.sm, o.se, d_status);
+  HIPCHK(hipGetLastError());
+  rc = read_status(st, false);
+  if (rc) return rc;
+  g.tab_groups = total;
+  *n_groups = total;
+  return SF_OK;
+}
+
+int sf_tabulate_fetch(int32_t *group_k, int32_t *group_j, int32_t *group_windows, int32_t *group_first_window,
+                      double *group_sum_z, double *group_sum_mfe, double *group_sum_ed) {
+  if (!g.init) return SF_ERR_NOT_INIT;
+  if (g.tab_groups < 0) return SF_ERR_BAD_ARG;  // no finished sf_tabulate_pairs
+  const int64_t n = g.tab_groups;
+  if (n == 0) return SF_OK;
+  TabOut o = tab_out_views(n);
+  hipStream_t st = g.stream;
+  if (group_k) HIPCHK(hipMemcpyAsync(group_k, o.gk, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+  if (group_j) HIPCHK(hipMemcpyAsync(group_j, o.gj, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+  if (group_windows) HIPCHK(hipMemcpyAsync(group_windows, o.gcount, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+  if (group_first_window) HIPCHK(hipMemcpyAsync(group_first_window, o.gfirst, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+  if (group_sum_z) HIPCHK(hipMemcpyAsync(group_sum_z, o.sz, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+  if (group_sum_mfe) HIPCHK(hipMemcpyAsync(group_sum_mfe, o.sm, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+  if (group_sum_ed) HIPCHK(hipMemcpyAsync(group_sum_ed, o.se, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return SF_OK;
 }
 
 int sf_last_status(void) {

@@ -98,20 +98,18 @@ def pair_partners(struct_matrix):
 
 
 class Tabulation:
-    """Per nucleotide k and partner j (j == k: unpaired): the windows that support the pair, in window order."""
+    """Per nucleotide k and partner j (j == k: unpaired): the windows that support the pair, in window order.
+    This class does the grouping on the host (numpy); DeviceTabulation hands it to the engine."""
 
     def __init__(self, table):
         n = len(table.starts)
         W = len(table.structs[0]) if n else 0
         if any(len(s) != W for s in table.structs) or any(len(s) != W for s in table.seqs):
             raise ValueError("windows of different lengths in one scan table")
-        S = np.frombuffer("".join(table.structs).encode("ascii"), dtype=np.uint8).reshape(n, W)
+        self._S = np.frombuffer("".join(table.structs).encode("ascii"), dtype=np.uint8).reshape(n, W)
         Q = np.frombuffer("".join(table.seqs).encode("ascii"), dtype=np.uint8).reshape(n, W)
-        part = pair_partners(S)
         pos = np.arange(W)[None, :]
         k = (table.starts[:, None] + pos).ravel()                      # coordinate of the nucleotide
-        j = np.where(part >= 0, table.starts[:, None] + part, table.starts[:, None] + pos).ravel()
-        win = np.repeat(np.arange(n), W)
         # nucleotide of every coordinate: the LAST window that covers it wins, as in NucleotideDictionary (:108-159)
         self.start_coordinate = int(table.starts[0])
         self.end_coordinate = int(table.starts[-1] + W - 1)
@@ -123,15 +121,48 @@ class Tabulation:
         self.nuc = nuc
         self.present = np.zeros(size, dtype=bool)
         self.present[k - lo] = True
-        # NucleotideDictionary keys in insertion order: first coordinate = start of the first window, last = end of the last
-        order = np.lexsort((win, j, k))  # groups (k, j) contiguous, windows ascending inside a group
-        self.k, self.j, self.win = k[order], j[order], win[order]
-        self.z = table.z[self.win]
-        self.mfe = table.mfe[self.win]
-        self.ed = table.ed[self.win]
+        self.table = table
         self.window_z = table.z
         self.id = table.id
         self.W = W
+        self._k = k
+
+    def groups(self):
+        """-> gk, gj, gcount, gfirst, gsum_z, gsum_mfe, gsum_ed: one entry per (nucleotide, partner) group, ordered by
+        nucleotide (the order inside one nucleotide is not relied upon); gfirst = first supporting window."""
+        table, W = self.table, self.W
+        n = len(table.starts)
+        part = pair_partners(self._S)
+        pos = np.arange(W)[None, :]
+        k = self._k
+        j = np.where(part >= 0, table.starts[:, None] + part, table.starts[:, None] + pos).ravel()
+        win = np.repeat(np.arange(n), W)
+        # NucleotideDictionary keys in insertion order: first coordinate = start of the first window, last = end of the last
+        order = np.lexsort((win, j, k))  # groups (k, j) contiguous, windows ascending inside a group
+        k, j, win = k[order], j[order], win[order]
+        new_group = np.ones(len(k), dtype=bool)
+        new_group[1:] = (k[1:] != k[:-1]) | (j[1:] != j[:-1])
+        gstart = np.nonzero(new_group)[0]
+        gcount = np.diff(np.append(gstart, len(k)))
+        return (k[gstart], j[gstart], gcount, win[gstart],     # first window of the group = dictionary insertion order
+                group_sums(table.z[win], gstart, gcount),      # np.sum of the group's values, window order
+                group_sums(table.mfe[win], gstart, gcount), group_sums(table.ed[win], gstart, gcount))
+
+
+class DeviceTabulation(Tabulation):
+    """The same table with the grouping and the sums done by the HIP engine (sf_tabulate_pairs): bracket matching per
+    window, one wave per nucleotide, numpy's summation order restated on the device — the arrays come back bit-equal
+    to Tabulation.groups().  Needs window starts in ascending order (every scan table has them)."""
+
+    def __init__(self, table, engine):
+        super().__init__(table)
+        self.engine = engine
+
+    def groups(self):
+        t = self.table
+        g = self.engine.tabulate_pairs(self._S, t.starts, t.z, t.mfe, t.ed)
+        return (g["k"].astype(np.int64), g["j"].astype(np.int64), g["windows"].astype(np.int64),
+                g["first_window"].astype(np.int64), g["sum_z"], g["sum_mfe"], g["sum_ed"])
 
 
 def _pairwise(M):
@@ -184,17 +215,10 @@ class FoldResult:
 def best_partners(tab, log_path=None):
     """ScanFold-Fold.py:704-846.  Returns a FoldResult with, per nucleotide coordinate (ascending):
     coord, best partner, mean z / mfe / ed of that pair, SumZ/#TotalWindows of it."""
-    k, j, win = tab.k, tab.j, tab.win
-    new_group = np.ones(len(k), dtype=bool)
-    new_group[1:] = (k[1:] != k[:-1]) | (j[1:] != j[:-1])
-    gstart = np.nonzero(new_group)[0]
-    gk, gj = k[gstart], j[gstart]
-    gcount = np.diff(np.append(gstart, len(k)))
-    gfirst = win[gstart]                                   # first window of the group = dictionary insertion order
-    gsum_z = group_sums(tab.z, gstart, gcount)             # np.sum of the group's values, window order
+    gk, gj, gcount, gfirst, gsum_z, gsum_mfe, gsum_ed = tab.groups()
     gmean_z = gsum_z / gcount
-    gmean_mfe = group_sums(tab.mfe, gstart, gcount) / gcount
-    gmean_ed = group_sums(tab.ed, gstart, gcount) / gcount
+    gmean_mfe = gsum_mfe / gcount
+    gmean_ed = gsum_ed / gcount
     # nucleotides
     new_k = np.ones(len(gk), dtype=bool)
     new_k[1:] = gk[1:] != gk[:-1]
@@ -346,9 +370,10 @@ def write_bp(tab, res, path, ident):
         f.write("".join(out))
 
 
-def fold(table, prefix, filt=-2, bp_path="final_partners_test.bp", write_log=True):
-    """The whole stage for one scan table; files are named like the reference's (`prefix` = "<input>.ScanFold.")."""
-    tab = Tabulation(table)
+def fold(table, prefix, filt=-2, bp_path="final_partners_test.bp", write_log=True, engine=None):
+    """The whole stage for one scan table; files are named like the reference's (`prefix` = "<input>.ScanFold.").
+    engine: a scanfold_amd Engine -> the pair tabulation runs on the GPU (DeviceTabulation); None -> numpy."""
+    tab = Tabulation(table) if engine is None else DeviceTabulation(table, engine)
     res = best_partners(tab, prefix + "log.txt" if write_log else None)
     compete(tab, res, prefix + "final_partners.txt")
     z = tab.window_z

@@ -7,7 +7,7 @@ Restates the scan section of /root/reference/ScanFold.py (:420-757) — the Scan
   md.max_bp_span = --span                                                   ScanFold.py:214-215
   --constraints: constrained native fold; --react: Deigan SHAPE term for the MFE only   ScanFold.py:508-544
 and then feeds the windows straight into the Fold stage (scanfold_amd.fold; ScanFold.py:564-677,1036-1453) without a
-TSV round trip.  Output: `<name>.win_W.stp_S.rnd_R.shfl_T.out` (the scan table, ScanFold.py:381,685) and the Fold
+TSV round trip; the pair tabulation of that stage runs on the GPU (sf_tabulate_pairs).  Output: `<name>.win_W.stp_S.rnd_R.shfl_T.out` (the scan table, ScanFold.py:381,685) and the Fold
 stage's files with the prefix `<that>.ScanFold.`, then the dot-bracket files (makedbn) and the motif extraction /
 refolds of ScanFold.py:1582-1776 (scanfold_amd.motifs: `<that>.ExtractedStructures.gff3`, `<that>_motif_<n>.dbn/.ct`).
 ScanFold.py's per-record directories, IGV wig exports and the full-length global refold are not reproduced.
@@ -208,7 +208,7 @@ def main(argv=None):
         if not args.dont_fold:
             table.id = read_name
             # ScanFold.py tabulates every window (its inline loop has no dropped first row, unlike ScanFold-Fold.py)
-            foldmod.fold(table, outname + ".ScanFold.", filt=int(args.f), bp_path=outname + ".bp")
+            foldmod.fold(table, outname + ".ScanFold.", filt=int(args.f), bp_path=outname + ".bp", engine=eng)
             for tag, label in (("no_filter", "NoFilter"), ("-1", "Zavg_-1"), ("-2", "Zavg_-2")):
                 writers.makedbn(outname + ".ScanFold." + tag, label)  # ScanFold.py:1487-1489
             if not args.dont_extract:

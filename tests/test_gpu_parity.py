@@ -574,3 +574,48 @@ def test_motif_refolds_on_gpu(gpu_engine, oracle, tmp_path, monkeypatch):
     finally:
         oracle.set_constraint(None, None)
     assert len(open("x.gff3").read().split("\n")) == 7
+
+
+def test_device_pair_tabulation_equals_host_grouping(gpu_engine):
+    """sf_tabulate_pairs (ScanFold-Fold.py:583-682,704-760): groups, first windows and numpy-order sums bit-equal to the
+    numpy grouping of scanfold_amd.fold on a real scan (W=120, step 1) and on synthetic tables with groups of more than
+    128 and 256 windows; the resident table of sf_scan_dev is read in place."""
+    import torch
+    from test_fold import _sorted_groups, _synthetic_table
+    from scanfold_amd import fold, scan_functions as sf
+    seq = synth_transcript(700, 21)
+    W, r = 120, 12
+    n = len(seq) - W + 1
+    res = gpu_engine.scan(seq, W, 1, 0, n, r, 1, 5, raw=True)
+    E = res["energies"].astype(np.float64) / 100.0
+    z = np.round((E[:, 0] - E.mean(axis=1)) / np.maximum(E.std(axis=1), 1e-9), 2)
+    starts = np.arange(1, n + 1)
+    structs = [bytes(row[:W]).decode() for row in res["structure"]]
+    table = fold.ScanTable("rec", starts, np.round(E[:, 0], 1), z, np.round(res["ens_div"], 2), [seq[s - 1:s - 1 + W] for s in starts],
+                           structs)
+    rng = np.random.default_rng(3)
+    tables = [table, _synthetic_table(rng, 330, 200, 1, n_structs=3, open_prob=0.1),
+              _synthetic_table(rng, 420, 400, 1, n_structs=2, open_prob=0.05), _synthetic_table(rng, 40, 33, 7, start=5)]
+    for t in tables:
+        host = _sorted_groups(fold.Tabulation(t).groups())
+        dev = fold.DeviceTabulation(t, gpu_engine).groups()
+        for a, b in zip(host, dev):
+            assert np.array_equal(a, np.asarray(b))
+    # the structure table where sf_scan_dev left it (rows of W + 1 bytes), never copied to the host
+    dev = torch.device("cuda", 0)
+    d_tr = torch.tensor(np.frombuffer(seq.encode(), dtype=np.uint8), device=dev)
+    d_en = torch.empty((n, r + 1), dtype=torch.int32, device=dev)
+    d_db = torch.zeros((n, W + 1), dtype=torch.uint8, device=dev)
+    d_cen = torch.zeros((n, W + 1), dtype=torch.uint8, device=dev)
+    d_div = torch.zeros(n, dtype=torch.float64, device=dev)
+    d_dg = torch.zeros(n, dtype=torch.float64, device=dev)
+    gpu_engine.scan_dev(d_tr.data_ptr(), len(seq), W, 1, 0, n, r, 1, 5, 0, d_en.data_ptr(), d_db.data_ptr(),
+                        d_cen.data_ptr(), d_div.data_ptr(), d_dg.data_ptr())
+    assert gpu_engine.last_status() == 0
+    g = gpu_engine.tabulate_pairs(d_db.data_ptr(), table.starts, table.z, table.mfe, table.ed, W=W, row_stride=W + 1,
+                                  on_device=True)
+    host = _sorted_groups(fold.Tabulation(table).groups())
+    for a, key in zip(host, ("k", "j", "windows", "first_window", "sum_z", "sum_mfe", "sum_ed")):
+        assert np.array_equal(a, g[key])
+    with pytest.raises(_lib.ScanFoldHipError, match="scan table"):
+        gpu_engine.tabulate_pairs(["((..", "...."], [1, 2], np.zeros(2), np.zeros(2), np.zeros(2))

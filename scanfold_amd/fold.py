@@ -295,21 +295,21 @@ def compete(tab, res, log_path=None):
     r_mfe, r_z, r_ed = _round2(res.best_mean_mfe), _round2(res.best_mean_z), _round2(res.best_mean_ed)
     r_tw = _round2(twz)
     cache = {}
+    coords_l, bj_l, twz_l = coords.tolist(), bj.tolist(), twz.tolist()
     for t in range(n):
-        kk = int(coords[t])
-        vj = int(bj[t])
+        kk = coords_l[t]
+        vj = bj_l[t]
         merged = []
         for c0 in (kk, vj):
             for p in competing(c0):
-                for c1 in (int(bj[p]), int(coords[p])):
+                for c1 in (bj_l[p], coords_l[p]):
                     lst = cache.get(c1)
                     if lst is None:
                         lst = cache[c1] = competing(c1)
                     merged.extend(lst)
         if merged:
-            m = np.asarray(merged)
-            b = int(m[np.argmin(twz[m])])  # the first of the smallest (min() over sums of one-element lists, :163-281)
-            bi, bjj = int(coords[b]), int(bj[b])
+            b = min(merged, key=twz_l.__getitem__)  # the first of the smallest (min() over sums of one-element lists, :163-281)
+            bi, bjj = coords_l[b], bj_l[b]
             bz_mfe, bz_z, bz_ed = r_mfe[b], r_tw[b], r_ed[b]
         else:
             b = None

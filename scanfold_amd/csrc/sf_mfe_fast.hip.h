@@ -81,6 +81,13 @@ struct SfFastParams {
   int16_t stack[64];
   int16_t d5[40], d3[40];
   uint8_t pair[64];  // [a*8+b]
+  // Special interior loops (stack, 1-nt bulge, 1x1, 1x2, 2x1, 2x2, 2x3, 3x2) read the enclosed cell from the bulge
+  // view CB = c + TerminalAU(reversed type); these images carry "- TerminalAU(inner type)" already, and the inner
+  // type comes reversed from rpair — no per-candidate arithmetic on types is left in the kernel.  int16, indexed
+  // like the blob's tables; int21b is corrected by its FIRST type index (the 2x1 orientation), the others by the second.
+  uint8_t rpair[64];   // rtype(pair[a][b])
+  int16_t stackT[64], mm23in[200];
+  int16_t int11T[8 * 8 * 25], int21a[8 * 8 * 125], int21b[8 * 8 * 125], int22T[8 * 8 * 625];
 };
 
 static inline void sf_fast_build_params(const SfDevParams &D, SfFastParams &F) {
@@ -126,7 +133,30 @@ static inline void sf_fast_build_params(const SfDevParams &D, SfFastParams &F) {
     for (int u = 0; u < 8; u++) F.stack[t * 8 + u] = clamp16(P.stack[t][u]);
   }
   for (int a = 0; a < 8; a++)
-    for (int b = 0; b < 8; b++) F.pair[a * 8 + b] = (uint8_t)D.pair[a][b];
+    for (int b = 0; b < 8; b++) {
+      const int t = D.pair[a][b];
+      F.pair[a * 8 + b] = (uint8_t)t;
+      F.rpair[a * 8 + b] = (uint8_t)((t && t < 7) ? (((t - 1) ^ 1) + 1) : t);
+    }
+  auto tau = [&P](int t) { return t > 2 ? P.TerminalAU : 0; };
+  auto off16 = [&clamp16](int32_t v, int t) { return v >= SF_INF ? (int16_t)32000 : clamp16(v - t); };
+  for (int t = 0; t < 8; t++)
+    for (int u = 0; u < 8; u++) {
+      F.stackT[t * 8 + u] = off16(P.stack[t][u], tau(u));
+      for (int a = 0; a < 5; a++)
+        for (int b = 0; b < 5; b++) {
+          F.int11T[((t * 8 + u) * 5 + a) * 5 + b] = off16(P.int11[t][u][a][b], tau(u));
+          for (int c = 0; c < 5; c++) {
+            F.int21a[(((t * 8 + u) * 5 + a) * 5 + b) * 5 + c] = off16(P.int21[t][u][a][b][c], tau(u));
+            F.int21b[(((t * 8 + u) * 5 + a) * 5 + b) * 5 + c] = off16(P.int21[t][u][a][b][c], tau(t));
+            for (int e = 0; e < 5; e++)
+              F.int22T[((((t * 8 + u) * 5 + a) * 5 + b) * 5 + c) * 5 + e] = off16(P.int22[t][u][a][b][c][e], tau(u));
+          }
+        }
+    }
+  for (int t = 0; t < 8; t++)
+    for (int a = 0; a < 5; a++)
+      for (int b = 0; b < 5; b++) F.mm23in[t * 25 + a * 5 + b] = off16(P.mismatch23I[t][a][b], tau(t));
 }
 
 // LDS carve (bytes); every piece a multiple of 4
@@ -136,9 +166,11 @@ struct SfFastLayout {
   int off_guard;  // per-wave copies of the size tables for the short diagonals (sf_fast_guard_tables)
   int total;
 };
-// int16 entries: mismatch23 rows 0..6 (175), five more mismatch tables rows 1..6 (150 each), stack (64), d5, d3 (40
-// each), pair (64 bytes), one pad, four size tables (32 each)
-#define SF_FAST_TAB_BYTES ((175 + 5 * 150 + 64 + 40 + 40 + 32 + 1 + 4 * 32) * 2)
+// int16 entries: mismatch23 rows 0..6 (175), five more mismatch tables rows 1..6 (150 each), stack (64; holds
+// stackT), d5, d3 (40 each), pair (64 bytes), one pad, four size tables (32 each), reversed pair types (64 bytes),
+// mismatch23 minus the terminal penalty of its type, rows 0..6 (175), one pad
+#define SF_FAST_TAB_OLD (175 + 5 * 150 + 64 + 40 + 40 + 32 + 1 + 4 * 32)
+#define SF_FAST_TAB_BYTES ((SF_FAST_TAB_OLD + 32 + 175 + 1) * 2)
 static inline __host__ __device__ SfFastLayout sf_fast_layout(int W) {
   SfFastLayout L;
   int tri = (W - 4) * W - (W * (W - 1) / 2 - 6);  // sum_{d=4}^{W-1} (W-d)
@@ -173,6 +205,8 @@ static inline int sf_fast_threads(int W) { return W <= 128 ? 256 : 512; }  // tw
 struct SfFastCtx {
   int16_t *fML, *CI, *C1N, *CB, *DMLr;
   const int16_t *tI, *t1n, *t23, *tM, *tH, *tStack, *tD5, *tD3;
+  const int16_t *t23in;    // mismatch23 - TerminalAU(its type): the inner side of 2x3 loops
+  const uint8_t *tRPair;   // reversed pair type of two bases
   const int16_t *tE;  // mismatchExt image (only where cg_ext is set)
   int cg_ext;         // 1: the c scratch holds c[i,j] + ExtLoop(i,j) (what the exterior sweep adds up); 0: c[i,j]
   const uint8_t *tPair, *S;
@@ -378,44 +412,47 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
     eh = SF_FAST_BIG;
     if (type && (!G || umax >= 0)) {
       const int TAU = X.TAU;
-      const sf_params_blob &P = X.D->P;
       const int tau_out = type > 2 ? TAU : 0;
       const int16_t *st = X.tStack + type * 8;
 #ifndef SF_ABL_RARE
+      // (every table below already carries "- TerminalAU(inner pair)": CB holds c + that term, see SfFastParams)
+      const uint8_t *RP = X.tRPair;
+      const unsigned tq = (unsigned)type * 8u;
       {  // stack
-        const int t2r = sfd_rtype(X.tPair[si1 * 8 + sj1]);
-        eh = sfd_min(eh, CBAT(ROW(0) + i0 + 1) - (t2r > 2 ? TAU : 0) + st[t2r]);
+        const int t2r = RP[si1 * 8 + sj1];
+        eh = sfd_min(eh, CBAT(ROW(0) + i0 + 1) + st[t2r]);
       }
       if (!G || umax >= 1) {  // one-nucleotide bulges keep the stack
         const int b1 = SF_UNI(uBN, 2);
         const int16_t *row = X.BN + 2 * (ROW(1) + i0);
-        const int ta = sfd_rtype(X.tPair[si1 * 8 + S[j - 2]]);  // (i+1, j-2)
-        eh = sfd_min(eh, row[2 * 1] - (ta > 2 ? TAU : 0) + b1 + st[ta]);
-        const int tb = sfd_rtype(X.tPair[S[i + 2] * 8 + sj1]);  // (i+2, j-1)
-        eh = sfd_min(eh, row[2 * 2] - (tb > 2 ? TAU : 0) + b1 + st[tb]);
+        const int ta = RP[si1 * 8 + S[j - 2]];  // (i+1, j-2)
+        eh = sfd_min(eh, row[2 * 1] + b1 + st[ta]);
+        const int tb = RP[S[i + 2] * 8 + sj1];  // (i+2, j-1)
+        eh = sfd_min(eh, row[2 * 2] + b1 + st[tb]);
       }
       if (!G || umax >= 2) {  // 1 x 1: (i+2, j-2)
-        const int t2r = sfd_rtype(X.tPair[S[i + 2] * 8 + S[j - 2]]);
-        eh = sfd_min(eh, CBAT(ROW(2) + i0 + 2) - (t2r > 2 ? TAU : 0) + P.int11[type][t2r][si1][sj1]);
+        const unsigned t2r = RP[S[i + 2] * 8 + S[j - 2]];
+        eh = sfd_min(eh, CBAT(ROW(2) + i0 + 2) + X.F->int11T[((tq + t2r) * 5u + si1) * 5u + sj1]);
       }
       if (!G || umax >= 3) {  // 1 x 2 and 2 x 1
         const int16_t *row = X.BN + 2 * (ROW(3) + i0);
-        const int ta = sfd_rtype(X.tPair[S[i + 2] * 8 + S[j - 3]]);  // (i+2, j-3), sq1 = S[j-2]
-        eh = sfd_min(eh, row[2 * 2] - (ta > 2 ? TAU : 0) + P.int21[type][ta][si1][S[j - 2]][sj1]);
-        const int tb = sfd_rtype(X.tPair[S[i + 3] * 8 + S[j - 2]]);  // (i+3, j-2), sp1 = S[i+2]
-        eh = sfd_min(eh, row[2 * 3] - (tb > 2 ? TAU : 0) + P.int21[tb][type][sj1][si1][S[i + 2]]);
+        const unsigned ta = RP[S[i + 2] * 8 + S[j - 3]];  // (i+2, j-3), sq1 = S[j-2]
+        eh = sfd_min(eh, row[2 * 2] + X.F->int21a[(((tq + ta) * 5u + si1) * 5u + S[j - 2]) * 5u + sj1]);
+        const unsigned tb = RP[S[i + 3] * 8 + S[j - 2]];  // (i+3, j-2), sp1 = S[i+2]
+        eh = sfd_min(eh, row[2 * 3] + X.F->int21b[(((tb * 8u + type) * 5u + sj1) * 5u + si1) * 5u + S[i + 2]]);
       }
       if (!G || umax >= 4) {  // 2 x 2: (i+3, j-3)
-        const int t2r = sfd_rtype(X.tPair[S[i + 3] * 8 + S[j - 3]]);
-        eh = sfd_min(eh, CBAT(ROW(4) + i0 + 3) - (t2r > 2 ? TAU : 0) + P.int22[type][t2r][si1][S[i + 2]][S[j - 2]][sj1]);
+        const unsigned t2r = RP[S[i + 3] * 8 + S[j - 3]];
+        eh = sfd_min(eh, CBAT(ROW(4) + i0 + 3) +
+                             X.F->int22T[((((tq + t2r) * 5u + si1) * 5u + S[i + 2]) * 5u + S[j - 2]) * 5u + sj1]);
       }
       if (!G || umax >= 5) {  // 2 x 3 and 3 x 2
         const int16_t *row = X.BN + 2 * (ROW(5) + i0);
         const int m23 = X.t23[SF_TIDX(type, si1, sj1)] + X.F->L23;
-        const int ta = sfd_rtype(X.tPair[S[i + 3] * 8 + S[j - 4]]);  // (i+3, j-4); sp1 = S[i+2], sq1 = S[j-3]
-        eh = sfd_min(eh, row[2 * 3] - (ta > 2 ? TAU : 0) + m23 + X.t23[SF_TIDX(ta, S[j - 3], S[i + 2])]);
-        const int tb = sfd_rtype(X.tPair[S[i + 4] * 8 + S[j - 3]]);  // (i+4, j-3); sp1 = S[i+3], sq1 = S[j-2]
-        eh = sfd_min(eh, row[2 * 4] - (tb > 2 ? TAU : 0) + m23 + X.t23[SF_TIDX(tb, S[j - 2], S[i + 3])]);
+        const int ta = RP[S[i + 3] * 8 + S[j - 4]];  // (i+3, j-4); sp1 = S[i+2], sq1 = S[j-3]
+        eh = sfd_min(eh, row[2 * 3] + m23 + X.t23in[SF_TIDX(ta, S[j - 3], S[i + 2])]);
+        const int tb = RP[S[i + 4] * 8 + S[j - 3]];  // (i+4, j-3); sp1 = S[i+3], sq1 = S[j-2]
+        eh = sfd_min(eh, row[2 * 4] + m23 + X.t23in[SF_TIDX(tb, S[j - 2], S[i + 3])]);
       }
 #endif
       // bulges (size u >= 2) and 1 x n loops (total size u >= 4), one rolling row per u
@@ -563,7 +600,7 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
       }
       // multiloop closed by (i,j)
       {
-        const int tr = sfd_rtype(type);
+        const int tr = X.tRPair[S[i] * 8 + S[j]];  // type != 0 here: the reversed type of the cell's own pair
         const int dml = dprev;  // multiloop split of (i+1, j-1): this thread's previous cell
         e = sfd_min(e, dml + X.tM[SF_TIDX(tr, sj1, si1)] + (tr > 2 ? TAU : 0) + X.MLintern + X.MLclosing);
       }
@@ -585,7 +622,7 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
   const int rbd = slotd * RW + i0;
   int f = SF_FAST_BIG, cx = SF_INF16;
   if (type) {
-    const int tr = sfd_rtype(type);
+    const int tr = X.tRPair[S[i] * 8 + S[j]];
     const int sp1 = S[i - 1], sq1 = S[j + 1];
     const int tau_in = tr > 2 ? X.TAU : 0;
     X.CI[rbd] = (int16_t)(c + X.tI[SF_TIDX(tr, sq1, sp1)]);
@@ -1054,6 +1091,9 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
   uint8_t *tPair = (uint8_t *)(tab + 1069);
   int16_t *guard = (int16_t *)(smem + Lo.off_guard);
   X.tPair = tPair;
+  uint8_t *tRPair = (uint8_t *)(tab + SF_FAST_TAB_OLD);
+  int16_t *t23in = tab + SF_FAST_TAB_OLD + 32;
+  X.tRPair = tRPair; X.t23in = t23in;
   (void)Lo.off_red;
   int32_t *flag = (int32_t *)(smem + Lo.off_flag);
   uint8_t *S = (uint8_t *)(smem + Lo.off_S);
@@ -1075,7 +1115,8 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
       tab[625 + x] = F->mmH[25 + x]; tab[775 + x] = F->mmExt[25 + x];
     }
   }
-  for (int x = tid; x < 64; x += NT) { tab[925 + x] = F->stack[x]; tPair[x] = F->pair[x]; }
+  for (int x = tid; x < 175; x += NT) t23in[x] = F->mm23in[x];
+  for (int x = tid; x < 64; x += NT) { tab[925 + x] = F->stackT[x]; tPair[x] = F->pair[x]; tRPair[x] = F->rpair[x]; }
   for (int x = tid; x < 40; x += NT) { tab[989 + x] = F->d5[x]; tab[1029 + x] = F->d3[x]; }
 
   {

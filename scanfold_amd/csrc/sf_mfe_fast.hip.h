@@ -59,6 +59,20 @@
 #ifndef SF_FAST_SPLIT
 #define SF_FAST_SPLIT 1  // long diagonals: the idle second wave of a group takes part of the cell's work
 #endif
+// split steps at W > 128 (four waves per diagonal): 1 = the group's outer waves help the two middle ones
+#ifndef SF_FAST_SPLIT_256
+#define SF_FAST_SPLIT_256 1
+#endif
+// split steps: the helper wave takes (terms / 2 - bias) terms of the multiloop split, the ones with the largest m.
+// NG = 128: none (the helper's special-loop work already balances the first wave; measured: any share, same time);
+// NG = 256: the split is most of a cell there
+#ifndef SF_DML_HELPER_BIAS_128
+#define SF_DML_HELPER_BIAS_128 100000
+#endif
+#ifndef SF_DML_HELPER_BIAS_256
+#define SF_DML_HELPER_BIAS_256 26
+#endif
+#define SF_DML_HELPER_BIAS(ng) ((ng) == 256 ? SF_DML_HELPER_BIAS_256 : SF_DML_HELPER_BIAS_128)
 #define SF_INF16 30000
 #define SF_FAST_THRESH 10000
 #define SF_FAST_OVF (-12000)
@@ -328,7 +342,8 @@ template <bool G, int WT, int SEC, bool CH = false, bool FOLD = false>
 __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, const int i, const bool valid,
                                              const int slot2, const int slotd, uint32_t (&HP)[14], int &ovf,
                                              const bool final_fml, const int fnb, int &fpart, int &dec, int &eh, int &e0,
-                                             const int16_t *uni, int &dprev) {
+                                             const int16_t *uni, int &dprev, const int dml_lo = SFD_TURN + 1,
+                                             const int dml_hi = 1 << 20) {
   // size tables [4][32]: asymmetry, loop initiation, 1xn, bulge (the kernel passes guarded copies on short diagonals)
   // third table: 32-bit pairs (bulge[u], 1xn term of total size u — 32767 for u < 4, where no 1xn loop exists)
   const int16_t *const uNIN = uni, *const uIL = uni + 32, *const uBN = uni + 64;
@@ -522,17 +537,19 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
     const int bB = d - 1 - H_;  // first m whose second operand lies in the left part
     int dec2 = SF_FAST_BIG;
     const int16_t *T = X.fML + i0;
-    if (bB > SFD_TURN + 1) {  // stretch 1, m = 4 .. bB-1: both operands step by +S (second operand in the right part)
-      const int m0 = SFD_TURN + 1;
-      sf_fast_split_stretch<true, true>(T, T + (W - d + m0) * S_ + d - 3, bB - m0, S_, dec, dec2);
+    // (a split step shares the terms between the waves of a cell: only m = dml_lo .. min(dml_hi, mend), wave-uniform)
+    const int lo = dml_lo, hi = sfd_min(mend, dml_hi);
+    {  // stretch 1, m = 4 .. bB-1: both operands step by +S (second operand in the right part)
+      const int m0 = sfd_max(SFD_TURN + 1, lo), m1 = sfd_min(bB - 1, hi);
+      if (m1 >= m0) sf_fast_split_stretch<true, true>(T + (m0 - 4) * S_, T + (W - d + m0) * S_ + d - 3, m1 - m0 + 1, S_, dec, dec2);
     }
     {  // stretch 2, m = max(4, bB) .. min(mend, H): first operand +S, second -(S-1) (both in the left part)
-      const int m0 = sfd_max(SFD_TURN + 1, bB), m1 = sfd_min(mend, H_);
+      const int m0 = sfd_max(sfd_max(SFD_TURN + 1, bB), lo), m1 = sfd_min(sfd_min(mend, H_), hi);
       if (m1 >= m0) sf_fast_split_stretch<true, false>(T + (m0 - 4) * S_, T + (d - 5 - m0) * S_ + m0 + 1, m1 - m0 + 1, S_, dec, dec2);
     }
-    if (mend > H_) {  // stretch 3, m = H+1 .. mend: both operands step by -(S-1) (first operand in the right part)
-      const int m0 = H_ + 1;
-      sf_fast_split_stretch<false, false>(T + (W - 1 - m0) * S_ + m0 - 3, T + (d - 5 - m0) * S_ + m0 + 1, mend - H_, S_, dec, dec2);
+    {  // stretch 3, m = H+1 .. mend: both operands step by -(S-1) (first operand in the right part)
+      const int m0 = sfd_max(H_ + 1, lo), m1 = hi;
+      if (m1 >= m0) sf_fast_split_stretch<false, false>(T + (W - 1 - m0) * S_ + m0 - 3, T + (d - 5 - m0) * S_ + m0 + 1, m1 - m0 + 1, S_, dec, dec2);
     }
     dec = sfd_min(dec, dec2);
   } else {
@@ -540,10 +557,11 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
     // wave-uniform differences, FBASE(m+1)-FBASE(m) = W-m: inside a batch of eight terms each address is the
     // previous one plus ONE uniform byte step (a single v_add with a scalar operand), the triangular part
     // -k(k-1)/2 of the step sequence is a compile-time load offset (pointers rebased by 56 bytes to keep it >= 0).
-    const char *pa = (const char *)(X.fML + i0) - 56;                                              // FBASE(4) = 0
-    const char *pb = (const char *)(X.fML + i0 + 1 + FBASE(d - SFD_TURN - 2) + SFD_TURN + 1) - 56;  // m = 4
-    int m = SFD_TURN + 1;
-    const int mend = d - SFD_TURN - 2;
+    // (a split step shares the terms between the waves of a cell: m = dml_lo .. min(dml_hi, d-5), wave-uniform)
+    int m = dml_lo;
+    const int mend = sfd_min(d - SFD_TURN - 2, dml_hi);
+    const char *pa = (const char *)(X.fML + i0 + FBASE(m)) - 56;                      // FBASE(4) = 0
+    const char *pb = (const char *)(X.fML + i0 + 1 + FBASE(d - m - 1) + m) - 56;
     int sa = 2 * (W - m), sb = 2 * (W - d + m + 1);
     int dec2 = SF_FAST_BIG;
     for (; m + 7 <= mend; m += 8) {
@@ -1134,10 +1152,19 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
   // group and centre-based mapping inside the group: v = (tg + OFF) mod NG, cell i = v - d/2
   const int grp = SF_WAVE_UNIFORM(tid / NG);  // a wave lies in one group: keep d, row slots, loop limits scalar
   const int tg = tid - grp * NG;
-  const int OFF = (NG > 64) ? (((W + 1) >> 1) - 32 + NG) & (NG - 1) : 0;
+  // CENTRE: the lane (of the group) around which the cells of the long diagonals gather.  NG = 128: lane 32, so the
+  // last 62 cells of a diagonal lie in the group's first wave; NG = 256: lane 128, so the last 126 lie in its two
+  // middle waves — the other waves of the group then work as helpers (see `split` below).
+  constexpr int CENTRE = (NG == 256) ? 128 : 32;
+  constexpr bool SHARE = SF_DML_HELPER_BIAS(NG) < 10000;  // the helper waves take part of the multiloop split
+  const int OFFs = ((W + 1) >> 1) - CENTRE;                  // signed: v = tg + OFFs (mod NG)
+  const int OFF = (NG > 64) ? (OFFs + NG) & (NG - 1) : 0;
   const int v = (tg + OFF) & (NG - 1);
-  // first even diagonal from which the cells of both groups lie in the lanes tg < 64 (W >= 64: OFF >= 0, no wrap)
-  const int split_d0 = (NG == 128 && W >= 64 && SF_FAST_SPLIT) ? ((sfd_max(sfd_max(SFD_MAXLOOP + 6, 2 * (OFF - 1)), 2 * (W - OFF - 63)) + 1) & ~1) : 1 << 30;
+  // first even diagonal from which the cells of both groups lie in the main lanes: tg in [0, 63] (NG = 128, W >= 64
+  // so that nothing wraps) or [64, 191] (NG = 256)
+  constexpr int MAIN_LO = (NG == 256) ? 64 : 0, MAIN_HI = (NG == 256) ? 191 : 63;
+  const bool can_split = SF_FAST_SPLIT && ((NG == 128 && W >= 64) || (NG == 256 && SF_FAST_SPLIT_256));
+  const int split_d0 = can_split ? ((sfd_max(sfd_max(SFD_MAXLOOP + 6, 2 * (MAIN_LO - 1 + OFFs)), 2 * (W - OFFs - MAIN_HI)) + 1) & ~1) : 1 << 30;
 
   // deferred exterior sweep: wave 3 (the helper of the odd group) works on the previous fold's scratch
   constexpr bool DEFER = SF_DEFER && (NG == 128);
@@ -1173,9 +1200,15 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
       // those cells, while the first does the generic-loop recurrence and the multiloop split; the partial
       // result crosses in LDS (in the C1N entry the cell will publish, unread until the next step) at a barrier,
       // then the first wave finishes the cell.  The dependent chain of such a step is ~45 % shorter.
-      const bool split = (NG == 128) && d0 >= split_d0;
-      const bool helper = split && tg >= 64;
-      const int i = (helper ? ((v - 64) & (NG - 1)) : v) - (d >> 1);
+      const bool split = d0 >= split_d0;
+      // helper lanes mirror a main lane 64 away: NG = 128: wave 1 -> wave 0; NG = 256: wave 0 -> wave 1, wave 3 -> wave 2
+      const bool helper = split && (NG == 256 ? (tg < 64 || tg >= 192) : tg >= 64);
+      const int vh = NG == 256 ? (tg < 64 ? v + 64 : v - 64) : v - 64;
+      const int i = (helper ? (vh & (NG - 1)) : v) - (d >> 1);
+      // split step: the multiloop split (d-8 terms, the part of a cell that grows with d) is shared with the helper
+      // wave: terms m >= dml_cut are the helper's (wave-uniform; both waves of a cell compute the same cut)
+      const int dml_terms = d - 2 * SFD_TURN - 2;  // m = 4 .. d-5
+      const int dml_cut = d - SFD_TURN - 1 - sfd_max(sfd_min(dml_terms / 2 - SF_DML_HELPER_BIAS(NG), dml_terms), 0);
       const bool valid = (d < W) && (i >= 1) && (i + d <= W);
       int fpart = SF_FAST_BIG;
       int dec = SF_FAST_BIG, eh = SF_FAST_BIG, e0 = SF_FAST_BIG;
@@ -1215,10 +1248,19 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
         if (d0 < SF_FAST_TINY_D0) sf_fast_cell<true, WT, SF_SEC_ALL, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev);
         else if (d0 < SF_FAST_CHUNK_D0) sf_fast_cell<false, WT, SF_SEC_ALL, true, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev);
         else if (!split) sf_fast_cell<false, WT, SF_SEC_ALL, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev);
-        else if (!helper) sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_DML, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev);
-        else {
-          sf_fast_cell<false, WT, SF_SEC_HELP, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev);
-          if (valid) X.BN[2 * (slotd * (W - 4) + i - 1) + 1] = (int16_t)sfd_min(eh, 32000);
+        else if (!helper) {
+          if (SHARE) sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_DML, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev, SFD_TURN + 1, dml_cut - 1);
+          else sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_DML, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev);
+        } else {
+          // the helper's results -> the entry the cell will publish (unread until the next step): eh in the C1N half,
+          // its part of the multiloop split in the CB half
+          if (SHARE) {
+            sf_fast_cell<false, WT, SF_SEC_HELP | SF_SEC_DML, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev, dml_cut);
+            if (valid) sf_stw(X.BN + 2 * (slotd * (W - 4) + i - 1), sf_pk(sfd_min(dec, 32000), sfd_min(eh, 32000)));
+          } else {
+            sf_fast_cell<false, WT, SF_SEC_HELP, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev);
+            if (valid) X.BN[2 * (slotd * (W - 4) + i - 1) + 1] = (int16_t)sfd_min(eh, 32000);
+          }
         }
       }
       if (sweep_now) {
@@ -1233,7 +1275,15 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
       if (split) {
         __syncthreads();
         if (!helper && __ballot(valid)) {
-          if (valid) eh = X.BN[2 * (slotd * (W - 4) + i - 1) + 1];
+          if (valid) {
+            if (SHARE) {
+              const uint32_t hw = sf_ldw(X.BN + 2 * (slotd * (W - 4) + i - 1));
+              eh = sf_hi(hw);
+              dec = sfd_min(dec, sf_lo(hw));
+            } else {
+              eh = X.BN[2 * (slotd * (W - 4) + i - 1) + 1];
+            }
+          }
           sf_fast_cell<false, WT, SF_SEC_FIN, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev);
         }
       }
@@ -1335,9 +1385,11 @@ static inline void sf_fast_geometry(int W, int n_cu, int n, int *grid, int *thre
   const SfFastLayout L = sf_fast_layout(W);
   const int nt = sf_fast_threads(W);
   int per_cu = (160 * 1024) / L.total;
-  const int by_waves = 32 / (nt / 64);
+  // The kernel is compiled for SF_FAST_WAVES_PER_SIMD waves per SIMD (128 VGPRs each): more workgroups than that
+  // cannot be resident however little LDS they need, and a persistent grid larger than what is resident runs its
+  // surplus workgroups as a second round (measured at W=100: 5 per CU 3.31 M folds/s, 4 per CU 4.12 M).
+  const int by_waves = (4 * SF_FAST_WAVES_PER_SIMD) / (nt / 64);
   if (per_cu > by_waves) per_cu = by_waves;
-  if (per_cu > 8) per_cu = 8;
   if (const char *e = getenv("SCANFOLD_MFE_BLOCKS_PER_CU")) {  // experiments: fewer resident workgroups per CU
     const int v = atoi(e);
     if (v >= 1 && v < per_cu) per_cu = v;

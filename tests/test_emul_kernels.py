@@ -46,6 +46,21 @@ def test_fast_kernel_odd_widths_and_traceback(emul, oracle):
             assert (db[k], e[k]) == oracle.mfe(bytes(arr[k]).decode()), (W, k)
 
 
+def test_fast_kernel_four_wave_groups_with_helper_waves(emul, oracle):
+    """W > 128: four waves per diagonal; from the diagonal where the cells fit the two middle waves on, the outer waves
+    mirror them (special loops + a share of the multiloop split).  Widths on both sides of every seam, biased
+    compositions (long helices: the multiloop split decides), MFE and traceback against the oracle."""
+    emul.load_params(params.default_params())
+    rng = np.random.default_rng(23)
+    for W in (129, 130, 146, 177, 200, 223, 256):
+        arr = random_seqs(rng, 2, W)
+        gc = np.frombuffer(b"GGGCCCAU", dtype=np.uint8)[rng.integers(0, 8, (1, W))]
+        arr = np.concatenate([arr, gc])
+        e, db = emul.mfe_trace_batch(arr)
+        for k in range(len(arr)):
+            assert (db[k], e[k]) == oracle.mfe(bytes(arr[k]).decode()), (W, k)
+
+
 def test_int16_overflow_falls_back_to_exact_kernel(emul, oracle):
     W = 100
     arr = np.zeros((2, W), dtype=np.uint8)

@@ -791,15 +791,6 @@ int sf_set_kernel_mode(int mode) {
   return SF_OK;
 }
 
-#ifdef SF_STAMP
-int sf_debug_stamps(unsigned long long *out) {  // diagnostic build only
-  HIPCHK(hipDeviceSynchronize());
-  HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(sf_stamp_acc), sizeof(unsigned long long) * 64));
-  HIPCHK(hipMemcpyFromSymbol(out + 64, HIP_SYMBOL(sf_stamp_step), sizeof(unsigned long long) * 128));  // out: 192 entries
-  HIPCHK(hipMemcpyFromSymbol(out + 192, HIP_SYMBOL(sf_pf_stamp_acc), sizeof(unsigned long long) * 32));  // out: 224 entries
-  return SF_OK;
-}
-#endif
 
 int sf_prof_reset(void) {
   if (!g.init) return SF_ERR_NOT_INIT;

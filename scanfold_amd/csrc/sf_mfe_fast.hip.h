@@ -273,29 +273,6 @@ __device__ __forceinline__ void sf_fast_split_stretch(const int16_t *pa, const i
     if (!AP) pa += (NB - 1) * sa;
     if (!BP) pb += (NB - 1) * sb;
     const int16_t *pal = pa + (len - NB) * sa, *pbl = pb + (len - NB) * sb;
-#ifdef SF_SPLIT_PIPE
-    // software pipeline: the reads of batch n+1 are issued before batch n is reduced
-    int a2[NB], b2[NB];
-#pragma unroll
-    for (int k = 0; k < NB; k++) {
-      a[k] = pa[AP ? k * S : (NB - 1 - k) * (S - 1)];
-      b[k] = pb[BP ? k * S : (NB - 1 - k) * (S - 1)];
-    }
-    for (int nb = (len - 1) / NB; nb > 0; --nb) {
-      pa += NB * sa;
-      pb += NB * sb;
-      const int16_t *qa = nb > 1 ? pa : pal, *qb = nb > 1 ? pb : pbl;
-#pragma unroll
-      for (int k = 0; k < NB; k++) {
-        a2[k] = qa[AP ? k * S : (NB - 1 - k) * (S - 1)];
-        b2[k] = qb[BP ? k * S : (NB - 1 - k) * (S - 1)];
-      }
-      SF_SPLIT_REDUCE()
-#pragma unroll
-      for (int k = 0; k < NB; k++) { a[k] = a2[k]; b[k] = b2[k]; }
-    }
-    SF_SPLIT_REDUCE()
-#else
     for (int nb = (len - 1) / NB; nb > 0; --nb) {
 #pragma unroll
       for (int k = 0; k < NB; k++) {
@@ -312,7 +289,6 @@ __device__ __forceinline__ void sf_fast_split_stretch(const int16_t *pa, const i
       b[k] = pbl[BP ? k * S : (NB - 1 - k) * (S - 1)];
     }
     SF_SPLIT_REDUCE()
-#endif
   } else {
 #pragma unroll
     for (int k = 0; k < NB; k++) {
@@ -374,7 +350,6 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
 
   if (SEC & SF_SEC_P1) {
   // ---- pass 1 (every cell): per-size minima of the generic interior candidates ----
-#ifndef SF_ABL_PASS1
   if (G) {
 #pragma unroll
     for (int u = 30; u >= 6; --u) {
@@ -418,7 +393,6 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
     HSET(1, sfd_min(row[3], row[4]) + SF_UNI(uNIN, 1));
   }
   if (!G || umax >= 4) HSET(0, X.CI[ROW(4) + i0 + 3] + SF_UNI(uNIN, 0));
-#endif
 
   }
 
@@ -429,7 +403,6 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
       const int TAU = X.TAU;
       const int tau_out = type > 2 ? TAU : 0;
       const int16_t *st = X.tStack + type * 8;
-#ifndef SF_ABL_RARE
       // (every table below already carries "- TerminalAU(inner pair)": CB holds c + that term, see SfFastParams)
       const uint8_t *RP = X.tRPair;
       const unsigned tq = (unsigned)type * 8u;
@@ -469,10 +442,8 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
         const int tb = RP[S[i + 4] * 8 + S[j - 3]];  // (i+4, j-3); sp1 = S[i+3], sq1 = S[j-2]
         eh = sfd_min(eh, row[2 * 4] + m23 + X.t23in[SF_TIDX(tb, S[j - 2], S[i + 3])]);
       }
-#endif
       // bulges (size u >= 2) and 1 x n loops (total size u >= 4), one rolling row per u
       int gb = SF_FAST_BIG, g1 = SF_FAST_BIG;
-#ifndef SF_ABL_PASS2
       if (G) {
 #pragma unroll
         for (int u = 2; u <= 30; ++u) {
@@ -514,7 +485,6 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
         }
         gb = sf_lo(acc); g1 = sf_hi(acc);
       }
-#endif
       eh = sfd_min(eh, gb + tau_out);
       eh = sfd_min(eh, g1 + X.t1n[SF_TIDX(type, si1, sj1)]);
     }
@@ -524,7 +494,6 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
   // (fewer values live across it) ----
   auto multiloop_split = [&]() {
     dec = SF_FAST_BIG;
-#ifndef SF_ABL_DML
   if (FOLD) {
     // min over m = 4 .. d-5 of fML[i, i+m] + fML[i+m+1, j] in the folded rectangle T (rows of S = W-3 entries):
     //   fML[i, i+m]   = T[FBASE(m) + i0]            moves by +S per m while m <= H, by -(S-1) per m after that;
@@ -586,7 +555,6 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
     }
     dec = sfd_min(dec, dec2);
   }
-#endif
     };
 
   // ---- hairpin, generic minima, multiloop closing (pairable cells): e0 ----
@@ -599,7 +567,6 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
       else e = X.D->hp_init[d - 1] + X.tH[SF_TIDX(type, si1, sj1)];
       if (!G || umax >= 0) {
         int gg = SF_FAST_BIG;
-#ifndef SF_ABL_PASS2
         if (G) {
 #pragma unroll
           for (int u = 6; u <= 30; ++u)
@@ -613,7 +580,6 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
             if (!CH || um >= 2 * pp + 4) ggp = sf_pkmin(ggp, sf_pkadd(HP[pp], sf_ldw(uIL + 2 * pp + 4)));
           gg = sfd_min(sf_lo(ggp), sf_hi(ggp));
         }
-#endif
         e = sfd_min(e, gg + X.tI[SF_TIDX(type, si1, sj1)]);
       }
       // multiloop closed by (i,j)
@@ -844,12 +810,6 @@ __device__ inline int sf_fast_traceback(const SfFastCtx &X, const int32_t *f5s, 
   return bad;
 }
 
-#ifdef SF_STAMP
-// diagnostic build only: per-wave cycle totals of block 0 (cell work / barrier 1 / odd finalize / barrier 2 / exterior)
-__device__ unsigned long long sf_stamp_acc[8][8];
-__device__ unsigned long long sf_stamp_step[128];  // wave 0 of block 0: whole step (cell .. odd finalize) by d0/2
-#define SF_T() __builtin_amdgcn_s_memtime()
-#endif
 
 // NG = threads per diagonal group.  The workgroup has two groups: group 0 handles the even diagonals, group 1
 // the odd ones.  c[.,.] of diagonal d+1 does not depend on diagonal d (an enclosed pair spans at most d-1, the
@@ -942,9 +902,6 @@ __device__ __forceinline__ void sf_fast_exterior(const SfFastCtx &X, const int W
     }
     return v;
   };
-#ifdef SF_STAMP
-  const unsigned long long te0 = SF_T();
-#endif
   constexpr int PF = 8;  // rows of c in flight
   int cb[PF][NQ];
   auto load_row = [&](const int i, int(&dst)[NQ]) {
@@ -956,12 +913,8 @@ __device__ __forceinline__ void sf_fast_exterior(const SfFastCtx &X, const int W
   };
 #pragma unroll
   for (int k = 0; k < PF; k++) load_row(1 + k, cb[k]);
-#ifdef SF_ABL_F5
-  for (int i0 = W; i0 <= W - SFD_TURN - 1; i0 += PF) {
-#else
 #pragma unroll 1
   for (int i0 = 1; i0 <= W - SFD_TURN - 1; i0 += PF) {
-#endif
 #pragma unroll
     for (int k = 0; k < PF; k++) {
       const int i = i0 + k;
@@ -995,9 +948,6 @@ __device__ __forceinline__ void sf_fast_exterior(const SfFastCtx &X, const int W
       }
     }
   }
-#ifdef SF_STAMP
-  const unsigned long long te1 = SF_T();
-#endif
   // the last columns: every row has been seen
   for (int jf = sfd_max(W - SFD_TURN - 1, 1); jf <= W; jf++) {
     f5prev = sfd_min(f5prev, column_min(jf));
@@ -1012,12 +962,6 @@ __device__ __forceinline__ void sf_fast_exterior(const SfFastCtx &X, const int W
       ovf_list[k] = seq;
     }
   }
-#ifdef SF_STAMP
-  if (blockIdx.x == 0 && lane == 0) {
-    const unsigned long long te2 = SF_T();
-    sf_stamp_acc[4][0] += te1 - te0; sf_stamp_acc[4][1] += te2 - te1;
-  }
-#endif
   // ---- traceback for the sequences whose structure is wanted (native windows) ----
   if (db_out && !over && (seq % trace_stride) == 0) {
     int16_t *stI = stack_area;
@@ -1229,9 +1173,6 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
         SF_WAVE_SYNC();
         uni = gt;
       }
-#ifdef SF_STAMP
-      const unsigned long long t0 = SF_T();
-#endif
       // deferred sweep of the previous fold: this step's rows are requested now, used after the wave's own work
       int dc[4][2];
       const bool sweep_now = defer_on && sweeper && split && Q.row > 0;
@@ -1240,11 +1181,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
         for (int k = 0; k < 4; k++)
           if (k < defer_rows) sf_defer_load(pend_cg, W, tid & 63, Q.row + k, dc[k][0], dc[k][1]);
       }
-#ifdef SF_ABL_CELL
-      if (0) {
-#else
       if (__ballot(valid)) {
-#endif
         if (d0 < SF_FAST_TINY_D0) sf_fast_cell<true, WT, SF_SEC_ALL, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev);
         else if (d0 < SF_FAST_CHUNK_D0) sf_fast_cell<false, WT, SF_SEC_ALL, true, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev);
         else if (!split) sf_fast_cell<false, WT, SF_SEC_ALL, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev);
@@ -1269,9 +1206,6 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
           if (k < defer_rows) sf_defer_row(Q, W, Q.row + k, dc[k][0], dc[k][1]);
         Q.row += defer_rows;
       }
-#ifdef SF_STAMP
-      const unsigned long long tA = SF_T();
-#endif
       if (split) {
         __syncthreads();
         if (!helper && __ballot(valid)) {
@@ -1287,13 +1221,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
           sf_fast_cell<false, WT, SF_SEC_FIN, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev);
         }
       }
-#ifdef SF_STAMP
-      const unsigned long long t1 = SF_T();
-#endif
       __syncthreads();
-#ifdef SF_STAMP
-      const unsigned long long t2 = SF_T();
-#endif
       // fML on the odd diagonal d0+1 = its provisional value (written by the odd group) min the two neighbours on
       // the even diagonal d0, now final.  The EVEN group does this: the only early reader of fML[d0+1] is the even
       // group's next cell (i-1, j+1), which needs the cells i-1 and i of it — so every even lane finishes BOTH
@@ -1316,26 +1244,12 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
         }
         fnb = sfd_min(g[0], g[1]) + X.MLbase;
       }
-#ifdef SF_STAMP
-      if (blockIdx.x == 0 && (tid & 63) == 0) {
-        const unsigned long long t3 = SF_T();
-        const int w = tid >> 6;
-        sf_stamp_acc[w][0] += t1 - t0; sf_stamp_acc[w][1] += t2 - t1; sf_stamp_acc[w][2] += t3 - t2;
-        sf_stamp_acc[w][5] += 1;
-        if (w == 0) sf_stamp_step[d0 >> 1] += t3 - t0;
-        if (w == 1) sf_stamp_step[64 + (d0 >> 1)] += tA - t0;
-        if (d0 >= 58) { sf_stamp_acc[w][6] += t1 - t0; sf_stamp_acc[w][7] += 1; sf_stamp_acc[w][3] += tA - t0; }
-      }
-#endif
       slot2 += 2; if (slot2 >= SF_FAST_NR) slot2 -= SF_FAST_NR;
       slotd += 2; if (slotd >= SF_FAST_NR) slotd -= SF_FAST_NR;
     }
 
     // ---- exterior loop f5[j] = min(f5[j-1], min_i f5[i-1] + c[i,j] + ExtLoop(i,j)) : wave 0 only ----
     // (sf_fast_exterior: lane = column, rows of c + ExtLoop stream from the scratch a few rows ahead)
-#ifdef SF_STAMP
-    const unsigned long long tf0 = SF_T();
-#endif
     if (ovf) flag[0] = 1;
     // the previous fold's deferred sweep ends here at the latest
     if (sweeper && Q.row > 0) sf_defer_finish(Q, pend_cg, W, tid & 63, out, ovf_cnt, ovf_list);
@@ -1355,17 +1269,11 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
     // (the scratch already holds c + ExtLoop: the sweep is one add and one min per cell; the mismatchExt table
     // above is for the traceback)
     int16_t *etab = nullptr;
-#ifdef SF_STAMP
-    if (blockIdx.x == 0 && tid == 0) sf_stamp_acc[4][2] += SF_T() - tf0;
-#endif
     if (tid < 64)
       sf_fast_exterior<NG / 64>(X, W, tid, seq, f5s, tExt, etab, flag, (int16_t *)(smem + Lo.off_cb),
                       (char *)(smem + Lo.off_cb + ((3 * (W + 8) * 2 + 3) & ~3)), out, ovf_cnt, ovf_list, trace_stride,
                       db_out, status);
     }
-#ifdef SF_STAMP
-    if (blockIdx.x == 0 && (tid & 63) == 0) sf_stamp_acc[tid >> 6][4] += SF_T() - tf0;
-#endif
   }
 #undef FBASE
 }

@@ -79,11 +79,6 @@ __device__ __forceinline__ double sf_lane_read_f64(const double v, const int l) 
 #endif
 }
 
-#ifdef SF_STAMP
-// diagnostic build only: cycles of block 0 in inside / exterior / outside / the rest of a fold, and the fold count
-__device__ unsigned long long sf_pf_stamp_acc[32];  // [0..2] phases, [3] folds, [8+team] / [16+team] work before the first barrier of an inside / outside column, [20] / [21] team 2 between the two barriers
-#define SF_PFT() __builtin_amdgcn_s_memtime()
-#endif
 
 template <int WT, bool SH>
 __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__restrict__ seqs, int n, int row_stride,
@@ -183,9 +178,6 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
     }
     __syncthreads();
 
-#ifdef SF_STAMP
-    const unsigned long long ts0 = SF_PFT();
-#endif
     // ================= inside: columns j ascending =================
     double H[27];
 #pragma unroll
@@ -215,9 +207,6 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
       __syncthreads();
     }
     for (int j = resume ? W - step + 1 : SFD_TURN + 2; j <= W + 1; j++) {
-#ifdef SF_STAMP
-      const unsigned long long tc0 = SF_PFT();
-#endif
       // j = W+1 only finishes qm of column W
       const int s = (j <= c - 1) ? c : c + SF_PFL_SLOTS;
       const int i = s - j, d = j - i;
@@ -379,13 +368,7 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
                            (type ? sfx_hairpin(D, X, S, i, j, type) : 0.0);
         }
       }
-#ifdef SF_STAMP
-      if (blockIdx.x == 0 && (tid & 127) == 0) sf_pf_stamp_acc[8 + team] += SF_PFT() - tc0;
-#endif
       __syncthreads();
-#ifdef SF_STAMP
-      const unsigned long long tc1 = SF_PFT();
-#endif
       if (team == 2 && qvalid) QMD(dq, i) = ZP[5 * VW + i] + ZP[4 * VW + i];
       if (team == 2 && valid) {
         const int type = OWN(i, j);
@@ -400,15 +383,9 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
         if (type) m1 += qbij * wml;
         qm1c[i] = m1;
       }
-#ifdef SF_STAMP
-      if (blockIdx.x == 0 && tid == 256) sf_pf_stamp_acc[20] += SF_PFT() - tc1;
-#endif
       __syncthreads();
     }
 
-#ifdef SF_STAMP
-    const unsigned long long ts1 = SF_PFT();
-#endif
     if (keep) {  // the inside state for the next window of the run (nothing below reads sv)
       for (int x = tid; x < 2 * NC + 12 * RP + 2 * VW + 8; x += SF_PFL_NT)
         sv[x] = x < SV_DER ? QB[x] : (x < SV_QM1 ? DER[x - SV_DER] : QM1[x - SV_QM1]);
@@ -505,17 +482,11 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
     }
     __syncthreads();
 
-#ifdef SF_STAMP
-    const unsigned long long ts2 = SF_PFT();
-#endif
     // ================= outside: columns l descending =================
 #pragma unroll
     for (int u = 0; u < 27; u++) H[u] = 0.0;
     double mbd = 0.0, cd = 0.0;
     for (int l = W; l >= SFD_TURN + 2; l--) {
-#ifdef SF_STAMP
-      const unsigned long long tc0 = SF_PFT();
-#endif
       const int s = (l <= c - 1) ? c : c + SF_PFL_SLOTS;
       const int k = s - l, d = l - k;
       const bool valid = (k >= 1) && (d >= SFD_TURN + 1);
@@ -681,13 +652,7 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
           ZP[5 * VW + k] = r1_part(1);
         }
       }
-#ifdef SF_STAMP
-      if (blockIdx.x == 0 && (tid & 127) == 0) sf_pf_stamp_acc[16 + team] += SF_PFT() - tc0;
-#endif
       __syncthreads();
-#ifdef SF_STAMP
-      const unsigned long long tc1 = SF_PFT();
-#endif
       if (team == 2 && valid) {
         const int type = OWN(k, l);
         const double qbkl = QBC(k, l);
@@ -711,17 +676,8 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
           if (centroid) { centroid[(size_t)fold * W1 + k - 1] = '('; centroid[(size_t)fold * W1 + l - 1] = ')'; }
         } else cd += p;
       }
-#ifdef SF_STAMP
-      if (blockIdx.x == 0 && tid == 256) sf_pf_stamp_acc[21] += SF_PFT() - tc1;
-#endif
       __syncthreads();
     }
-#ifdef SF_STAMP
-    if (blockIdx.x == 0 && tid == 0) {
-      const unsigned long long ts3 = SF_PFT();
-      sf_pf_stamp_acc[0] += ts1 - ts0; sf_pf_stamp_acc[1] += ts2 - ts1; sf_pf_stamp_acc[2] += ts3 - ts2; sf_pf_stamp_acc[3] += 1;
-    }
-#endif
     mbd = sf_block_sum(mbd, red);
     __syncthreads();
     cd = sf_block_sum(cd, red);

@@ -59,6 +59,11 @@
 #ifndef SF_FAST_SPLIT
 #define SF_FAST_SPLIT 1  // long diagonals: the idle second wave of a group takes part of the cell's work
 #endif
+// split steps at W <= 128: 1 = ONE helper wave serves both diagonals of a step, on a compacted list of the cells that
+// can pair (3 of 8): the special / bulge / 1xn block runs once per step instead of twice
+#ifndef SF_HELP_MERGE
+#define SF_HELP_MERGE 1
+#endif
 // split steps at W > 128 (four waves per diagonal): 1 = the group's outer waves help the two middle ones
 #ifndef SF_FAST_SPLIT_256
 #define SF_FAST_SPLIT_256 1
@@ -176,7 +181,7 @@ static inline void sf_fast_build_params(const SfDevParams &D, SfFastParams &F) {
 // LDS carve (bytes); every piece a multiple of 4
 struct SfFastLayout {
   int tri;  // int16 entries of the fML triangle (diagonals >= 4)
-  int off_ci, off_c1n, off_cb, off_dml, off_tab, off_red, off_flag, off_S;
+  int off_ci, off_c1n, off_cb, off_dml, off_list, off_tab, off_red, off_flag, off_S;
   int off_guard;  // per-wave copies of the size tables for the short diagonals (sf_fast_guard_tables)
   int total;
 };
@@ -199,6 +204,11 @@ static inline __host__ __device__ SfFastLayout sf_fast_layout(int W) {
   L.off_c1n = o; o += roll;
   L.off_cb = o; o += roll;
   L.off_dml = o;  // (end of the rolling tables; the rolling rows of multiloop-split minima that used to follow are gone)
+  // W <= 128 (merged helper, see the kernel): the interleaved bulge / 1xn table gets row NR = a copy of its row 0, so
+  // that "the row after row r" exists for every r, and each of the two helper waves a 128-byte list of cells
+  if (W <= 128 && SF_HELP_MERGE) o += RW * 4;
+  L.off_list = o;
+  if (W <= 128 && SF_HELP_MERGE) o += 2 * 128;
   L.off_tab = o; o += SF_FAST_TAB_BYTES;
   L.off_red = o;  // (unused)
   L.off_flag = o; o += 4;
@@ -229,6 +239,7 @@ struct SfFastCtx {
   int16_t *cg;
   int W, TAU, MLbase, MLclosing, MLintern;
   int fold;     // 1: the fML area is the folded rectangle (W > 128), 0: the triangle
+  int bn_dup;   // 1: BN has a row NR that mirrors row 0 (merged helper)
   int maxd;     // largest allowed j - i of a base pair (max_bp_span - 1)
   const int16_t *uNIN, *uIL, *uL1N, *uBUL;  // size-dependent terms, LDS copies (uniform reads)
   int16_t *BN;  // sf_mfe_fast_kernel: the bulge and 1xn rolling tables interleaved, entry x = (CB[x], C1N[x]) in one
@@ -610,7 +621,9 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
     const int sp1 = S[i - 1], sq1 = S[j + 1];
     const int tau_in = tr > 2 ? X.TAU : 0;
     X.CI[rbd] = (int16_t)(c + X.tI[SF_TIDX(tr, sq1, sp1)]);
-    sf_stw(X.BN + 2 * rbd, sf_pk(c + tau_in, c + X.t1n[SF_TIDX(tr, sq1, sp1)]));  // (CB, C1N)
+    const uint32_t bn = sf_pk(c + tau_in, c + X.t1n[SF_TIDX(tr, sq1, sp1)]);  // (CB, C1N)
+    sf_stw(X.BN + 2 * rbd, bn);
+    if (X.bn_dup && slotd == 0) sf_stw(X.BN + 2 * (SF_FAST_NR * RW + i0), bn);
     // E_MLstem and ExtLoop of (type, S[i-1], S[j+1]) differ in the mismatch table only; at the sequence ends both
     // are a dangle
     int stem, ext;
@@ -622,6 +635,7 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
     cx = sfd_min(c + ext + tau_in, SF_INF16);
   } else {
     X.CI[rbd] = SF_INF16; sf_stw(X.BN + 2 * rbd, sf_pk(SF_INF16, SF_INF16));
+    if (X.bn_dup && slotd == 0) sf_stw(X.BN + 2 * (SF_FAST_NR * RW + i0), sf_pk(SF_INF16, SF_INF16));
   }
   // the scratch (row i, column j: the exterior sweep reads rows coalesced) takes c + ExtLoop, the only form the
   // sweep needs; the traceback (native windows only) subtracts the term again (sf_fast_c).  (Storing only the cells
@@ -1061,6 +1075,9 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
   uint8_t *S = (uint8_t *)(smem + Lo.off_S);
   X.S = S;
   X.D = D; X.F = F; X.W = W; X.fold = FOLD; X.maxd = D->max_pair_dist;
+  constexpr bool MERGE = SF_HELP_MERGE && (NG == 128);
+  X.bn_dup = MERGE;
+  uint8_t *const cell_list = (uint8_t *)(smem + Lo.off_list);
   X.TAU = D->P.TerminalAU; X.MLbase = D->P.MLbase; X.MLclosing = D->P.MLclosing; X.MLintern = D->P.MLintern[1];
   // exterior pass aliases (the rolling CI area is dead by then)
   int32_t *f5s = (int32_t *)(smem + Lo.off_ci);
@@ -1092,7 +1109,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
   }
   // the rolling tables start out as "no structure": the guarded short-diagonal code reads rows no diagonal of the
   // first fold has written yet (later folds find the previous fold's energies there, which is as good)
-  for (int x = tid; x < (Lo.off_dml - Lo.off_ci) / 2; x += NT) X.CI[x] = SF_INF16;
+  for (int x = tid; x < (Lo.off_list - Lo.off_ci) / 2; x += NT) X.CI[x] = SF_INF16;
   // group and centre-based mapping inside the group: v = (tg + OFF) mod NG, cell i = v - d/2
   const int grp = SF_WAVE_UNIFORM(tid / NG);  // a wave lies in one group: keep d, row slots, loop limits scalar
   const int tg = tid - grp * NG;
@@ -1137,6 +1154,25 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
 
     // this thread's diagonal in the step that starts at the even diagonal d0 is d0 + grp
     int slot2 = (SFD_TURN + 1 + grp - 2) % SF_FAST_NR, slotd = (SFD_TURN + 1 + grp) % SF_FAST_NR;
+    // Merged helper: the cells of the diagonals dd0 and dd0+1 that can pair, as a helper wave sees them (lane -> mirror
+    // cell; i is the same on both diagonals since (dd0 + 1) >> 1 == dd0 >> 1).  Entry = i, +128 for the odd diagonal,
+    // even diagonal first; byte 127 of the buffer = the number of entries (<= 124).  Built by wave 3 one step ahead
+    // (two buffers, by step parity), read by wave 1 (entries 0..63) and wave 3 (entries 64.., rarely any).
+    auto build_list = [&](const int dd0) {
+      const int lane = tid & 63;
+      const int d1 = dd0 + 1;
+      const int iH = ((v - 64) & (NG - 1)) - (dd0 >> 1);
+      const bool vA = (dd0 < W) && (iH >= 1) && (iH + dd0 <= W), vB = (d1 < W) && (iH >= 1) && (iH + d1 <= W);
+      const int tA = (vA && dd0 <= X.maxd) ? X.tPair[S[iH] * 8 + S[iH + dd0]] : 0;
+      const int tB = (vB && d1 <= X.maxd) ? X.tPair[S[iH] * 8 + S[iH + d1]] : 0;
+      const unsigned long long mA = __ballot(tA != 0), mB = __ballot(tB != 0);
+      const int cA = __popcll(mA);
+      uint8_t *list = cell_list + (((dd0 >> 1) & 1) << 7);
+      const unsigned long long below = (1ull << lane) - 1ull;
+      if (tA) list[__popcll(mA & below)] = (uint8_t)iH;
+      if (tB) list[cA + __popcll(mB & below)] = (uint8_t)(iH | 128);
+      if (lane == 0) list[127] = (uint8_t)(cA + __popcll(mB));
+    };
     for (int d0 = SFD_TURN + 1; d0 < W; d0 += 2) {
       const int d = d0 + grp;
       // Long diagonals (d0 >= split_d0): the cells of a group fit its first wave, so the second wave — which would
@@ -1188,6 +1224,28 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
         else if (!helper) {
           if (SHARE) sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_DML, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev, SFD_TURN + 1, dml_cut - 1);
           else sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_DML, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev);
+        } else if (MERGE) {
+          // Merged helper (W <= 128).  ONE helper wave serves both diagonals of the step: it works on the list of the
+          // cells of d0 and d0+1 that can pair (build_list above; 3 of 8 cells, so ordinary sequences fit wave 1's 64
+          // lanes; entries 64.. go to wave 3).  A lane's cell may lie on either diagonal: the rolling rows of d0+1 are
+          // the rows of d0 plus one (the extra table row makes that true at the ring's seam), so the lane-dependent
+          // part is a pointer offset and everything scalar stays scalar.
+          const int lane = tid & 63;
+          const uint8_t *list = cell_list + (((d0 >> 1) & 1) << 7);
+          const int cT = SF_WAVE_UNIFORM((int)list[127]);
+          const int e = (grp << 6) + lane;  // wave 1: entries 0..63, wave 3: 64..127
+          if (SF_WAVE_UNIFORM(cT > (grp << 6))) {
+            const bool vC = e < cT;
+            const int ent = vC ? list[e] : 1;
+            const int g = ent >> 7, iC = ent & 127;
+            const int s2 = slot2 - grp < 0 ? slot2 - grp + SF_FAST_NR : slot2 - grp;      // the even group's rows
+            const int sd0 = slotd - grp < 0 ? slotd - grp + SF_FAST_NR : slotd - grp;
+            const int sd1 = sd0 + 1 >= SF_FAST_NR ? 0 : sd0 + 1;
+            SfFastCtx Xh = X;
+            Xh.BN = X.BN + 2 * g * (W - 4);
+            sf_fast_cell<false, WT, SF_SEC_HELP, false, FOLD>(Xh, d0 + g, iC, vC, s2, sd0, H, ovf, false, fnb, fpart, dec, eh, e0, uni, dprev);
+            if (vC) X.BN[2 * ((g ? sd1 : sd0) * (W - 4) + iC - 1) + 1] = (int16_t)sfd_min(eh, 32000);
+          }
         } else {
           // the helper's results -> the entry the cell will publish (unread until the next step): eh in the C1N half,
           // its part of the multiloop split in the CB half
@@ -1206,6 +1264,8 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
           if (k < defer_rows) sf_defer_row(Q, W, Q.row + k, dc[k][0], dc[k][1]);
         Q.row += defer_rows;
       }
+      // merged helper: wave 3 lists the next step's cells (the barriers of this step order the list before its readers)
+      if (MERGE && grp == 1 && tg >= 64 && d0 + 2 >= split_d0 && d0 + 2 < W) build_list(d0 + 2);
       if (split) {
         __syncthreads();
         if (!helper && __ballot(valid)) {

@@ -312,6 +312,18 @@ __device__ __forceinline__ void sf_fast_split_stretch(const int16_t *pa, const i
 #undef SF_SPLIT_REDUCE
 }
 
+// (CB, C1N) of the cell at column i0 of a row into the interleaved bulge / 1xn table; w points at the cell's own word.
+// SHIFT: the C1N half belongs in the previous word (column 0's is never read: 1xn candidates start at column 2).
+template <bool SHIFT>
+__device__ __forceinline__ void sf_fast_publish_bn(int16_t *w, const int i0, const uint32_t bn) {
+  if (SHIFT) {
+    w[0] = (int16_t)sf_lo(bn);
+    if (i0 > 0) w[-1] = (int16_t)sf_hi(bn);
+  } else {
+    sf_stw(w, bn);
+  }
+}
+
 // One anti-diagonal for one thread.  H: this parity's per-size minima of the generic candidates of the
 // enclosed cell (i+1, j-1) on entry, of (i, j) on exit.  slot2 = (d-2) mod NR, slotd = d mod NR.
 // G ("guarded"): d < 36, the loop-size limit d-6 is below MAXLOOP and every size is tested against it;
@@ -334,8 +346,11 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
   // size tables [4][32]: asymmetry, loop initiation, 1xn, bulge (the kernel passes guarded copies on short diagonals)
   // third table: 32-bit pairs (bulge[u], 1xn term of total size u — 32767 for u < 4, where no 1xn loop exists)
   const int16_t *const uNIN = uni, *const uIL = uni + 32, *const uBN = uni + 64;
+// Narrow kernel (SHIFT): word x of a row holds (CB[x], C1N[x+1]) — the two left-edge candidates of a size, CB at column
+// 1 and C1N at column 2, are then ONE word.  Wide kernel: (CB[x], C1N[x]).
+  constexpr bool SHIFT = !FOLD;
 #define CBAT(x) X.BN[2 * (x)]
-#define C1NAT(x) X.BN[2 * (x) + 1]
+#define C1NAT(x) X.BN[2 * ((x) - (SHIFT ? 1 : 0)) + 1]
 // H[x] (x = size - 4) lives in the int16 halves of HP[x/2]: 14 registers instead of 27 under the 128-VGPR cap
 #define HGET(x) (((x)&1) ? ((int)HP[(x) >> 1] >> 16) : (int)(int16_t)(HP[(x) >> 1] & 0xffffu))
 #define HSET(x, v)                                                                                       \
@@ -479,8 +494,9 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
             const int u = ub + k;
             if (u <= 30) {
               const int16_t *t = X.BN + 2 * (ROW(u) + i0);
-              w0[k] = sf_ldw(t + 2 * 1); w1[k] = sf_ldw(t + 2 * 2);
-              w2[k] = sf_ldw(t + 2 * u); w3[k] = sf_ldw(t + 2 * (u + 1));
+              w0[k] = sf_ldw(t + 2 * 1);
+              if (!SHIFT) w1[k] = sf_ldw(t + 2 * 2);
+              w2[k] = sf_ldw(t + 2 * (SHIFT ? u - 1 : u)); w3[k] = sf_ldw(t + 2 * (u + 1));
               wt[k] = sf_ldw(uBN + 2 * u);
             }
           }
@@ -488,7 +504,7 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
           for (int k = 0; k < 2; k++) {
             const int u = ub + k;
             if (u <= 30) {
-              const uint32_t x = (w0[k] & 0xffffu) | (w1[k] & 0xffff0000u);  // (CB[1], C1N[2])
+              const uint32_t x = SHIFT ? w0[k] : ((w0[k] & 0xffffu) | (w1[k] & 0xffff0000u));  // (CB[1], C1N[2])
               const uint32_t y = (w3[k] & 0xffffu) | (w2[k] & 0xffff0000u);  // (CB[1+u], C1N[u])
               acc = sf_pkmin(acc, sf_pkadd(sf_pkmin(x, y), wt[k]));
             }
@@ -622,8 +638,8 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
     const int tau_in = tr > 2 ? X.TAU : 0;
     X.CI[rbd] = (int16_t)(c + X.tI[SF_TIDX(tr, sq1, sp1)]);
     const uint32_t bn = sf_pk(c + tau_in, c + X.t1n[SF_TIDX(tr, sq1, sp1)]);  // (CB, C1N)
-    sf_stw(X.BN + 2 * rbd, bn);
-    if (X.bn_dup && slotd == 0) sf_stw(X.BN + 2 * (SF_FAST_NR * RW + i0), bn);
+    sf_fast_publish_bn<SHIFT>(X.BN + 2 * rbd, i0, bn);
+    if (X.bn_dup && slotd == 0) sf_fast_publish_bn<SHIFT>(X.BN + 2 * (SF_FAST_NR * RW + i0), i0, bn);
     // E_MLstem and ExtLoop of (type, S[i-1], S[j+1]) differ in the mismatch table only; at the sequence ends both
     // are a dangle
     int stem, ext;
@@ -634,8 +650,8 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
     f = c + stem + tau_in + X.MLintern;
     cx = sfd_min(c + ext + tau_in, SF_INF16);
   } else {
-    X.CI[rbd] = SF_INF16; sf_stw(X.BN + 2 * rbd, sf_pk(SF_INF16, SF_INF16));
-    if (X.bn_dup && slotd == 0) sf_stw(X.BN + 2 * (SF_FAST_NR * RW + i0), sf_pk(SF_INF16, SF_INF16));
+    X.CI[rbd] = SF_INF16; sf_fast_publish_bn<SHIFT>(X.BN + 2 * rbd, i0, sf_pk(SF_INF16, SF_INF16));
+    if (X.bn_dup && slotd == 0) sf_fast_publish_bn<SHIFT>(X.BN + 2 * (SF_FAST_NR * RW + i0), i0, sf_pk(SF_INF16, SF_INF16));
   }
   // the scratch (row i, column j: the exterior sweep reads rows coalesced) takes c + ExtLoop, the only form the
   // sweep needs; the traceback (native windows only) subtracts the term again (sf_fast_c).  (Storing only the cells

@@ -42,7 +42,7 @@ N = 131072.0
 per_fold = {k: v / N for k, v in sq.items()}
 out = {"source": "tools/r02_run.sh on MI355X; rocprofv3 --pmc passes, one counter group per run",
        "hbm_bytes_per_launch": (2 * fetch.get("FETCH_SIZE", 0) + write.get("WRITE_SIZE", 0)) * 1024,
-       "hbm_note": "MFE kernel of one cfg3 step (3 017 981 folds): 2 x FETCH_SIZE (gfx950 reports half of a read) + WRITE_SIZE, KB -> bytes",
+       "hbm_note": "MFE kernel launch of one cfg3 step (3 017 981 folds, the largest dispatch of the pass): 2 x FETCH_SIZE (gfx950 reports half of a read) + WRITE_SIZE, KB -> bytes; L2 <-> fabric traffic, Infinity-Cache hits included (profiles/r02/mfe_scratch_traffic.txt)",
        "fetch_size_kb": fetch.get("FETCH_SIZE"), "write_size_kb": write.get("WRITE_SIZE"),
        "per_fold_counters_W120": per_fold}
 if per_fold.get("SQ_WAVE_CYCLES"):

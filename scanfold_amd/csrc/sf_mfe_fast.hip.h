@@ -78,6 +78,14 @@
 #define SF_DML_HELPER_BIAS_256 26
 #endif
 #define SF_DML_HELPER_BIAS(ng) ((ng) == 256 ? SF_DML_HELPER_BIAS_256 : SF_DML_HELPER_BIAS_128)
+// loop sizes per batch of reads in the bulge / 1xn minima (narrow / wide kernel; measured 2, 3, 4, 6: W=120 best at
+// 3 by 0.6 %, W=200 at 6 by 3.5 %)
+#ifndef SF_HELP_NB_128
+#define SF_HELP_NB_128 3
+#endif
+#ifndef SF_HELP_NB_256
+#define SF_HELP_NB_256 6
+#endif
 #define SF_INF16 30000
 #define SF_FAST_THRESH 10000
 #define SF_FAST_OVF (-12000)
@@ -483,14 +491,15 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
         // The candidates of size u are CB[1], CB[1+u] and C1N[2], C1N[u] of row u: with the two tables interleaved
         // they are the low / high halves of the word pairs (1, 2) and (u, u+1) — two two-word reads; one
         // bit-select each puts (bulge, 1xn) candidates side by side, and the rest is packed: min, saturating
-        // add of the (bulge[u], 1xn[u]) weights (one uniform read), min.  Batches of two sizes.
+        // add of the (bulge[u], 1xn[u]) weights (one uniform read), min.  Batches of SF_HELP_NB sizes.
         uint32_t acc = sf_pk(32767, 32767);
+        constexpr int SF_HELP_NB = FOLD ? SF_HELP_NB_256 : SF_HELP_NB_128;
 #pragma unroll
-        for (int ub = 2; ub <= 30; ub += 2) {
+        for (int ub = 2; ub <= 30; ub += SF_HELP_NB) {
           if (CH && ub > um) continue;
-          uint32_t w0[2], w1[2], w2[2], w3[2], wt[2];
+          uint32_t w0[SF_HELP_NB], w1[SF_HELP_NB], w2[SF_HELP_NB], w3[SF_HELP_NB], wt[SF_HELP_NB];
 #pragma unroll
-          for (int k = 0; k < 2; k++) {
+          for (int k = 0; k < SF_HELP_NB; k++) {
             const int u = ub + k;
             if (u <= 30) {
               const int16_t *t = X.BN + 2 * (ROW(u) + i0);
@@ -501,7 +510,7 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
             }
           }
 #pragma unroll
-          for (int k = 0; k < 2; k++) {
+          for (int k = 0; k < SF_HELP_NB; k++) {
             const int u = ub + k;
             if (u <= 30) {
               const uint32_t x = SHIFT ? w0[k] : ((w0[k] & 0xffffu) | (w1[k] & 0xffff0000u));  // (CB[1], C1N[2])

@@ -13,9 +13,11 @@ bad = 0
 ALPH = np.frombuffer(b"ACGU", dtype=np.uint8)
 def seqs(n, W, p):
     return ALPH[rng.choice(4, size=(n, W), p=p)]
-comps = {"uniform": [.25, .25, .25, .25], "GC-rich": [.1, .4, .4, .1], "AU-rich": [.4, .1, .1, .4], "GU-rich": [.05, .05, .45, .45]}
+comps = {"uniform": [.25, .25, .25, .25], "GC-rich": [.1, .4, .4, .1], "AU-rich": [.4, .1, .1, .4], "GU-rich": [.05, .05, .45, .45],
+         "GC-only": [0, .5, .5, 0]}  # GC-only: half of all cells pair (more than 64 pairable cells on a split step: the merged helper's second chunk)
 t0 = time.time()
-for W, n in ((120, 40000), (100, 8000), (64, 8000), (37, 8000), (127, 4000), (128, 4000), (200, 1500), (16, 4000)):
+for W, n in ((120, 40000), (100, 8000), (80, 4000), (64, 8000), (37, 8000), (127, 4000), (128, 4000), (146, 1500), (160, 1500), (200, 1500),
+             (16, 4000)):
     for cname, p in comps.items():
         arr = seqs(n if cname == "uniform" else n // 4, W, p)
         ref = oracle.mfe_batch(arr)

@@ -307,18 +307,19 @@ int launch_mfe(const uint8_t *d_seqs, int n, int W, int32_t *d_out, hipStream_t 
     if (rc) return rc;
     if ((rc = prof.end(st))) return rc;
   } else {
-    rc = ensure(g.ovf, sizeof(int) * ((size_t)n + 1));
+    rc = ensure(g.ovf, sizeof(int) * ((size_t)n + 2));
     if (rc) return rc;
-    int *d_cnt = (int *)g.ovf.p, *d_list = d_cnt + 1;
-    HIPCHK(hipMemsetAsync(d_cnt, 0, sizeof(int), st));
+    // [overflow count][work counter][overflow list]: the counter (+ grid size) hands out the folds beyond each workgroup's first
+    int *d_cnt = (int *)g.ovf.p, *d_work = d_cnt + 1, *d_list = d_cnt + 2;
     int grid = 0, threads = 0;
     size_t lds = 0, scratch_bytes = 0;
     sf_fast_geometry(W, g.n_cu, n, &grid, &threads, &lds, &scratch_bytes);
+    HIPCHK(hipMemsetAsync(d_cnt, 0, 2 * sizeof(int), st));
     rc = ensure(g.fast_scratch, scratch_bytes);
     if (rc) return rc;
     if ((rc = prof.begin(st))) return rc;
     sf_fast_launch(grid, threads, lds, st, d_seqs, n, W, (const SfDevParams *)g.dP, (const SfFastParams *)g.dF,
-                     (int16_t *)g.fast_scratch.p, d_out, d_cnt, d_list, trace_stride, d_db, (int *)g.status.p);
+                     (int16_t *)g.fast_scratch.p, d_out, d_cnt, d_list, trace_stride, d_db, (int *)g.status.p, d_work);
     HIPCHK(hipGetLastError());
     if ((rc = prof.end(st))) return rc;
     // folds that left the int16 range are redone exactly

@@ -189,7 +189,7 @@ static inline void sf_fast_build_params(const SfDevParams &D, SfFastParams &F) {
 // LDS carve (bytes); every piece a multiple of 4
 struct SfFastLayout {
   int tri;  // int16 entries of the fML triangle (diagonals >= 4)
-  int off_ci, off_c1n, off_cb, off_dml, off_list, off_tab, off_red, off_flag, off_S;
+  int off_ci, off_c1n, off_cb, off_dml, off_list, off_next, off_tab, off_red, off_flag, off_S;
   int off_guard;  // per-wave copies of the size tables for the short diagonals (sf_fast_guard_tables)
   int total;
 };
@@ -214,12 +214,19 @@ static inline __host__ __device__ SfFastLayout sf_fast_layout(int W) {
   L.off_dml = o;  // (end of the rolling tables; the rolling rows of multiloop-split minima that used to follow are gone)
   // W <= 128 (merged helper, see the kernel): the interleaved bulge / 1xn table gets row NR = a copy of its row 0, so
   // that "the row after row r" exists for every r, and each of the two helper waves a 128-byte list of cells
-  if (W <= 128 && SF_HELP_MERGE) o += RW * 4;
+  // (ring row 0 only ever holds the diagonals NR, 2 NR, ...: at most W - NR cells)
+  if (W <= 128 && SF_HELP_MERGE && W > SF_FAST_NR) o += (W - SF_FAST_NR) * 4;
   L.off_list = o;
   if (W <= 128 && SF_HELP_MERGE) o += 2 * 128;
+  // (What follows the rolling tables matters: on the short diagonals the straight-line cell code reads candidates of
+  // loop sizes that do not exist yet — up to 23 words past the end of a row, past the end of the last row into
+  // whatever comes next — and relies on finding energy-sized values there (they get a weight of 32767 and saturate).
+  // The mirror row and the parameter tables are that; the cell list is never in reach where it is written (W >= 64),
+  // and is filled with "no structure" where it is not; the two control words below sit behind the tables.)
   L.off_tab = o; o += SF_FAST_TAB_BYTES;
   L.off_red = o;  // (unused)
   L.off_flag = o; o += 4;
+  L.off_next = o; o += 4;  // index of the workgroup's next fold (dynamic distribution)
   L.off_S = o; o += (W + 2 + 3) & ~3;
   // 256 bytes per wave, needed while d < 36 only: from W = 96 on they lie in the end of the fML triangle, whose
   // last 45 diagonals (>= 2 kB from W = 96 on, first written at d = W-45 >= 51) are still unused by then
@@ -1070,7 +1077,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
                                                              int16_t *__restrict__ cg_all, int32_t *__restrict__ out,
                                                              int *__restrict__ ovf_cnt, int *__restrict__ ovf_list,
                                                              int trace_stride, char *__restrict__ db_out,
-                                                             int *__restrict__ status) {
+                                                             int *__restrict__ status, int *__restrict__ work_ctr) {
   constexpr int NT = 2 * NG;
   constexpr bool FOLD = (NG == 256);  // W > 128: fML in the folded rectangle (see the file header)
   const int W = WT ? WT : Wrt;
@@ -1134,7 +1141,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
   }
   // the rolling tables start out as "no structure": the guarded short-diagonal code reads rows no diagonal of the
   // first fold has written yet (later folds find the previous fold's energies there, which is as good)
-  for (int x = tid; x < (Lo.off_list - Lo.off_ci) / 2; x += NT) X.CI[x] = SF_INF16;
+  for (int x = tid; x < (Lo.off_tab - Lo.off_ci) / 2; x += NT) X.CI[x] = SF_INF16;  // incl. the mirror row and the cell lists
   // group and centre-based mapping inside the group: v = (tg + OFF) mod NG, cell i = v - d/2
   const int grp = SF_WAVE_UNIFORM(tid / NG);  // a wave lies in one group: keep d, row slots, loop limits scalar
   const int tg = tid - grp * NG;
@@ -1163,13 +1170,23 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
   int cur_buf = 0;
   const int16_t *pend_cg = cg_pair;
 
-  for (int seq = blockIdx.x; seq < n; seq += gridDim.x) {
+  // Folds are handed out dynamically: a workgroup's first fold is its block index, every further one comes from a
+  // device-wide counter (zeroed by the host; grid size + its value).  The folds cost the same number of instructions, but
+  // the workgroups do not run at the same speed — with a static deal (fold b, b + grid, ...) the slowest of 1024
+  // took 897 ms for its 2 947 folds at cfg3 while the mean took 772 ms, and the launch lasts as long as the slowest.
+  // The index of the NEXT fold is requested at the start of a fold (one atomic by thread 0), parked in LDS two steps
+  // later, and read by everybody one step after that: its latency is never waited for.
+  int *const next_slot = (int *)(smem + Lo.off_next);
+  int seq = blockIdx.x;
+  while (seq < n) {
     const uint8_t *src = seqs + (size_t)seq * W;
     X.cg = cg_pair + (size_t)cur_buf * SF_CG_ENTRIES(W);
     __syncthreads();
     for (int x = tid; x < W; x += NT) S[x + 1] = sf_encode_nt(src[x]);
-    if (tid == 0) { S[0] = 0; S[W + 1] = 0; flag[0] = 0; }
+    int fetched = 0;
+    if (tid == 0) { S[0] = 0; S[W + 1] = 0; flag[0] = 0; fetched = (int)gridDim.x + atomicAdd(work_ctr, 1); }
     __syncthreads();
+    int next_seq = n;  // (set in the third step; W >= 16 has at least five)
     int ovf = 0;
     uint32_t H[14];  // packed int16 pairs, see HGET/HSET
     int dprev = SF_INF16;   // multiloop split of this thread's previous cell (diagonals 2, 3: none)
@@ -1200,6 +1217,8 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
     };
     for (int d0 = SFD_TURN + 1; d0 < W; d0 += 2) {
       const int d = d0 + grp;
+      if (d0 == SFD_TURN + 1 + 2 && tid == 0) *next_slot = fetched;            // the barriers of this step publish it
+      if (d0 == SFD_TURN + 1 + 4) next_seq = SF_WAVE_UNIFORM(*next_slot);
       // Long diagonals (d0 >= split_d0): the cells of a group fit its first wave, so the second wave — which would
       // idle — mirrors it (same lane -> same cell) and takes the special loops and the bulge / 1xn minima of
       // those cells, while the first does the generic-loop recurrence and the multiloop split; the partial
@@ -1339,7 +1358,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
     // the previous fold's deferred sweep ends here at the latest
     if (sweeper && Q.row > 0) sf_defer_finish(Q, pend_cg, W, tid & 63, out, ovf_cnt, ovf_list);
     const bool want_trace_now = db_out && (seq % trace_stride) == 0;
-    const bool last_fold = seq + (int)gridDim.x >= n;
+    const bool last_fold = next_seq >= n;
     if (defer_on && !want_trace_now && !last_fold) {
       // hand this fold's scratch to the next fold's helper wave
       __syncthreads();  // every thread's overflow flag and scratch stores are in
@@ -1359,6 +1378,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
                       (char *)(smem + Lo.off_cb + ((3 * (W + 8) * 2 + 3) & ~3)), out, ovf_cnt, ovf_list, trace_stride,
                       db_out, status);
     }
+    seq = next_seq;
   }
 #undef FBASE
 }

@@ -619,3 +619,18 @@ def test_device_pair_tabulation_equals_host_grouping(gpu_engine):
         assert np.array_equal(a, g[key])
     with pytest.raises(_lib.ScanFoldHipError, match="scan table"):
         gpu_engine.tabulate_pairs(["((..", "...."], [1, 2], np.zeros(2), np.zeros(2), np.zeros(2))
+
+
+def test_dynamic_fold_distribution_large_batches(gpu_engine, oracle):
+    """The batched MFE kernel hands folds to its persistent workgroups through a device-wide counter, so which
+    workgroup folds what — and after which other fold — changes from run to run.  Batches large enough for the fold
+    indices to exceed 16 bits (an index word once sat where the short-diagonal code reads past the rolling tables):
+    two runs must agree everywhere, and a sample spread over the whole batch must match the oracle."""
+    rng = np.random.default_rng(2026)
+    for W, n in ((200, 70000), (120, 140000), (131, 40000), (40, 140000)):
+        arr = random_seqs(rng, n, W)
+        e1 = gpu_engine.mfe_batch(arr)
+        e2 = gpu_engine.mfe_batch(arr)
+        assert (e1 == e2).all(), (W, int((e1 != e2).sum()))
+        pick = np.unique(np.concatenate([rng.integers(0, n, 900), np.arange(n - 300, n), np.arange(32768 - 150, 32768 + 150)]))
+        assert (oracle.mfe_batch(arr[pick]) == e1[pick]).all(), W

@@ -61,6 +61,12 @@
 #endif
 // split steps at W <= 128: 1 = ONE helper wave serves both diagonals of a step, on a compacted list of the cells that
 // can pair (3 of 8): the special / bulge / 1xn block runs once per step instead of twice
+// (W < SF_HELP_MERGE_MAXW only.  With folds handed out dynamically the merge measures +3.6 % at W=80, +2.3 % at W=100,
+// +1.1 % at W=110, +1.5 % at W=116 and -2.9 % at W=120, -1.4 % at W=128: the compacted lanes read scattered words, three or four deep
+// in the LDS banks, and at the widths where LDS cycles are tightest that costs more than the saved pass.)
+#ifndef SF_HELP_MERGE_MAXW
+#define SF_HELP_MERGE_MAXW 118
+#endif
 #ifndef SF_HELP_MERGE
 #define SF_HELP_MERGE 1
 #endif
@@ -212,12 +218,12 @@ static inline __host__ __device__ SfFastLayout sf_fast_layout(int W) {
   L.off_c1n = o; o += roll;
   L.off_cb = o; o += roll;
   L.off_dml = o;  // (end of the rolling tables; the rolling rows of multiloop-split minima that used to follow are gone)
-  // W <= 128 (merged helper, see the kernel): the interleaved bulge / 1xn table gets row NR = a copy of its row 0, so
+  // W < SF_HELP_MERGE_MAXW (merged helper, see the kernel): the interleaved bulge / 1xn table gets row NR = a copy of its row 0, so
   // that "the row after row r" exists for every r, and each of the two helper waves a 128-byte list of cells
   // (ring row 0 only ever holds the diagonals NR, 2 NR, ...: at most W - NR cells)
-  if (W <= 128 && SF_HELP_MERGE && W > SF_FAST_NR) o += (W - SF_FAST_NR) * 4;
+  if (W < SF_HELP_MERGE_MAXW && SF_HELP_MERGE && W > SF_FAST_NR) o += (W - SF_FAST_NR) * 4;
   L.off_list = o;
-  if (W <= 128 && SF_HELP_MERGE) o += 2 * 128;
+  if (W < SF_HELP_MERGE_MAXW && SF_HELP_MERGE) o += 2 * 128;
   // (What follows the rolling tables matters: on the short diagonals the straight-line cell code reads candidates of
   // loop sizes that do not exist yet — up to 23 words past the end of a row, past the end of the last row into
   // whatever comes next — and relies on finding energy-sized values there (they get a weight of 32767 and saturate).
@@ -1070,7 +1076,8 @@ __device__ __forceinline__ void sf_defer_finish(SfDeferred &Q, const int16_t *cg
   Q.row = 0;
 }
 
-template <int NG, int WT>
+// MG: the merged helper (narrow kernel, W < SF_HELP_MERGE_MAXW; the launcher picks the instantiation)
+template <int NG, int WT, bool MG = false>
 __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_kernel(const uint8_t *__restrict__ seqs, int n, int Wrt,
                                                              const SfDevParams *__restrict__ D,
                                                              const SfFastParams *__restrict__ F,
@@ -1107,7 +1114,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
   uint8_t *S = (uint8_t *)(smem + Lo.off_S);
   X.S = S;
   X.D = D; X.F = F; X.W = W; X.fold = FOLD; X.maxd = D->max_pair_dist;
-  constexpr bool MERGE = SF_HELP_MERGE && (NG == 128);
+  constexpr bool MERGE = MG && SF_HELP_MERGE && (NG == 128);
   X.bn_dup = MERGE;
   uint8_t *const cell_list = (uint8_t *)(smem + Lo.off_list);
   X.TAU = D->P.TerminalAU; X.MLbase = D->P.MLbase; X.MLclosing = D->P.MLclosing; X.MLintern = D->P.MLintern[1];
@@ -1322,6 +1329,9 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
               eh = X.BN[2 * (slotd * (W - 4) + i - 1) + 1];
             }
           }
+          // (with the shifted 1xn view the slot just read is where the NEXT lane's cell publishes its C1N: every lane
+          // of the wave has read before any lane stores — program order on the GPU, made explicit for the emulation)
+          SF_WAVE_SYNC();
           sf_fast_cell<false, WT, SF_SEC_FIN, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev);
         }
       }
@@ -1386,6 +1396,8 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
 static inline hipError_t sf_fast_configure() {
   hipError_t e = hipFuncSetAttribute((const void *)sf_mfe_fast_kernel<128, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void *)sf_mfe_fast_kernel<128, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void *)sf_mfe_fast_kernel<128, 120>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void *)sf_mfe_fast_kernel<256, 200>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1423,6 +1435,7 @@ template <typename... A>
 static inline void sf_fast_launch(int grid, int threads, size_t lds, hipStream_t st, const uint8_t *seqs, int n, int W,
                                   A... args) {
   if (threads == 256 && W == 120) SF_LAUNCH((sf_mfe_fast_kernel<128, 120>), grid, 256, lds, st, seqs, n, W, args...);
+  else if (threads == 256 && W < SF_HELP_MERGE_MAXW && SF_HELP_MERGE) SF_LAUNCH((sf_mfe_fast_kernel<128, 0, true>), grid, 256, lds, st, seqs, n, W, args...);
   else if (threads == 256) SF_LAUNCH((sf_mfe_fast_kernel<128, 0>), grid, 256, lds, st, seqs, n, W, args...);
   else if (W == 200) SF_LAUNCH((sf_mfe_fast_kernel<256, 200>), grid, 512, lds, st, seqs, n, W, args...);
   else SF_LAUNCH((sf_mfe_fast_kernel<256, 0>), grid, 512, lds, st, seqs, n, W, args...);

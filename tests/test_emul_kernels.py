@@ -46,6 +46,18 @@ def test_fast_kernel_odd_widths_and_traceback(emul, oracle):
             assert (db[k], e[k]) == oracle.mfe(bytes(arr[k]).decode()), (W, k)
 
 
+def test_fast_kernel_split_steps_on_many_sequences(emul, oracle):
+    """Both helper flavours of the narrow kernel on enough sequences for rare orderings to show (the emulation runs the
+    lanes of a wave one after the other, starting anywhere: a lane that publishes into its neighbour's exchange slot
+    before the neighbour has read it is found here, not on the GPU): merged helper (W < 118) and one helper per
+    diagonal (W >= 118)."""
+    emul.load_params(params.default_params())
+    rng = np.random.default_rng(77)
+    for W in (80, 100, 117, 118, 120, 124, 128):
+        arr = random_seqs(rng, 24, W)
+        assert (emul.mfe_batch(arr) == oracle.mfe_batch(arr)).all(), W
+
+
 def test_fast_kernel_four_wave_groups_with_helper_waves(emul, oracle):
     """W > 128: four waves per diagonal; from the diagonal where the cells fit the two middle waves on, the outer waves
     mirror them (special loops + a share of the multiloop split).  Widths on both sides of every seam, biased

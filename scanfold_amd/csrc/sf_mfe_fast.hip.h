@@ -367,9 +367,9 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
   // size tables [4][32]: asymmetry, loop initiation, 1xn, bulge (the kernel passes guarded copies on short diagonals)
   // third table: 32-bit pairs (bulge[u], 1xn term of total size u — 32767 for u < 4, where no 1xn loop exists)
   const int16_t *const uNIN = uni, *const uIL = uni + 32, *const uBN = uni + 64;
-// Narrow kernel (SHIFT): word x of a row holds (CB[x], C1N[x+1]) — the two left-edge candidates of a size, CB at column
-// 1 and C1N at column 2, are then ONE word.  Wide kernel: (CB[x], C1N[x]).
-  constexpr bool SHIFT = !FOLD;
+// Word x of a row holds (CB[x], C1N[x+1]) — the two left-edge candidates of a size, CB at column 1 and C1N at column
+// 2, are then ONE word.  (SHIFT = false: (CB[x], C1N[x]), the layout until late in round 2.)
+  constexpr bool SHIFT = true;
 #define CBAT(x) X.BN[2 * (x)]
 #define C1NAT(x) X.BN[2 * ((x) - (SHIFT ? 1 : 0)) + 1]
 // H[x] (x = size - 4) lives in the int16 halves of HP[x/2]: 14 registers instead of 27 under the 128-VGPR cap
@@ -1295,17 +1295,21 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
             SfFastCtx Xh = X;
             Xh.BN = X.BN + 2 * g * (W - 4);
             sf_fast_cell<false, WT, SF_SEC_HELP, false, FOLD>(Xh, d0 + g, iC, vC, s2, sd0, H, ovf, false, fnb, fpart, dec, eh, e0, uni, dprev);
-            if (vC) X.BN[2 * ((g ? sd1 : sd0) * (W - 4) + iC - 1) + 1] = (int16_t)sfd_min(eh, 32000);
+            if (vC) X.BN[2 * ((g ? sd1 : sd0) * (W - 4) + iC - 1)] = (int16_t)sfd_min(eh, 32000);
           }
         } else {
-          // the helper's results -> the entry the cell will publish (unread until the next step): eh in the C1N half,
-          // its part of the multiloop split in the CB half
+          // the helper's results -> the cell's OWN entries of the row it is about to publish (unread until the next
+          // step, and rewritten by nobody but the cell's own lane): eh in the CB half of its word, its part of the
+          // multiloop split in its CI entry
           if (SHARE) {
             sf_fast_cell<false, WT, SF_SEC_HELP | SF_SEC_DML, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev, dml_cut);
-            if (valid) sf_stw(X.BN + 2 * (slotd * (W - 4) + i - 1), sf_pk(sfd_min(dec, 32000), sfd_min(eh, 32000)));
+            if (valid) {
+              X.BN[2 * (slotd * (W - 4) + i - 1)] = (int16_t)sfd_min(eh, 32000);
+              X.CI[slotd * (W - 4) + i - 1] = (int16_t)sfd_min(dec, 32000);
+            }
           } else {
             sf_fast_cell<false, WT, SF_SEC_HELP, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev);
-            if (valid) X.BN[2 * (slotd * (W - 4) + i - 1) + 1] = (int16_t)sfd_min(eh, 32000);
+            if (valid) X.BN[2 * (slotd * (W - 4) + i - 1)] = (int16_t)sfd_min(eh, 32000);
           }
         }
       }
@@ -1321,17 +1325,9 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
         __syncthreads();
         if (!helper && __ballot(valid)) {
           if (valid) {
-            if (SHARE) {
-              const uint32_t hw = sf_ldw(X.BN + 2 * (slotd * (W - 4) + i - 1));
-              eh = sf_hi(hw);
-              dec = sfd_min(dec, sf_lo(hw));
-            } else {
-              eh = X.BN[2 * (slotd * (W - 4) + i - 1) + 1];
-            }
+            eh = X.BN[2 * (slotd * (W - 4) + i - 1)];
+            if (SHARE) dec = sfd_min(dec, (int)X.CI[slotd * (W - 4) + i - 1]);
           }
-          // (with the shifted 1xn view the slot just read is where the NEXT lane's cell publishes its C1N: every lane
-          // of the wave has read before any lane stores — program order on the GPU, made explicit for the emulation)
-          SF_WAVE_SYNC();
           sf_fast_cell<false, WT, SF_SEC_FIN, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev);
         }
       }

@@ -1026,7 +1026,7 @@ __device__ __forceinline__ void sf_fast_exterior(const SfFastCtx &X, const int W
   }
 }
 
-// Deferred exterior sweep (W <= 128 only).  A fold whose structure is not wanted does not run its exterior sweep at
+// Deferred exterior sweep.  A fold whose structure is not wanted does not run its exterior sweep at
 // its own end — one wave working for ~50 k cycles while the fold's other three wait at the next barrier, 8 % of a
 // fold's residency — but hands its c + ExtLoop scratch (the workgroup owns two, used alternately) to the NEXT fold:
 // the helper wave of the odd diagonal group sweeps SF_DEFER_ROWS rows of it in every step of the long-diagonal
@@ -1035,35 +1035,50 @@ __device__ __forceinline__ void sf_fast_exterior(const SfFastCtx &X, const int W
 #ifndef SF_DEFER
 #define SF_DEFER 1
 #endif
+#ifndef SF_DEFER_256
+#define SF_DEFER_256 1  // the wide kernel defers too (four columns per lane)
+#endif
+template <int NQ>
 struct SfDeferred {
-  int P0, P1, f5p;  // lane l: running minima of columns l+1 and l+65; f5[row-1]
+  int P[NQ], f5p;   // lane l: running minima of columns l+1, l+65, (l+129, l+193); f5[row-1]
   int row;          // next row to sweep (1-based); 0 = nothing pending
   int seq, over;    // the pending fold's index and its int16-overflow flag
 };
-__device__ __forceinline__ void sf_defer_load(const int16_t *cgp, const int W, const int lane, const int i, int &c0, int &c1) {
-  const int j0 = lane + 1, j1 = lane + 65;
-  c0 = (i <= W - SFD_TURN - 1 && j0 <= W && i + SFD_TURN + 1 <= j0) ? (int)cgp[SF_CGIDX(i, j0)] : SF_INF16;
-  c1 = (i <= W - SFD_TURN - 1 && j1 <= W && i + SFD_TURN + 1 <= j1) ? (int)cgp[SF_CGIDX(i, j1)] : SF_INF16;
+template <int NQ>
+__device__ __forceinline__ void sf_defer_load(const int16_t *cgp, const int W, const int lane, const int i, int (&c)[NQ]) {
+#pragma unroll
+  for (int q = 0; q < NQ; q++) {
+    const int j = lane + 1 + 64 * q;
+    c[q] = (i <= W - SFD_TURN - 1 && j <= W && i + SFD_TURN + 1 <= j) ? (int)cgp[SF_CGIDX(i, j)] : SF_INF16;
+  }
 }
-__device__ __forceinline__ int sf_defer_colmin(const SfDeferred &Q, const int jf) {  // P of column jf from its lane
-  const int l = (jf - 1) & 63;
-  const int v0 = SF_LANE_READ(Q.P0, l), v1 = SF_LANE_READ(Q.P1, l);
-  return (jf - 1) >> 6 ? v1 : v0;
+template <int NQ>
+__device__ __forceinline__ int sf_defer_colmin(const SfDeferred<NQ> &Q, const int jf) {  // P of column jf from its lane
+  const int l = (jf - 1) & 63, h = (jf - 1) >> 6;
+  int v = SF_LANE_READ(Q.P[0], l);
+#pragma unroll
+  for (int q = 1; q < NQ; q++) {
+    const int vq = SF_LANE_READ(Q.P[q], l);
+    v = h == q ? vq : v;
+  }
+  return v;
 }
-__device__ __forceinline__ void sf_defer_row(SfDeferred &Q, const int W, const int i, const int c0, const int c1) {
+template <int NQ>
+__device__ __forceinline__ void sf_defer_row(SfDeferred<NQ> &Q, const int W, const int i, const int (&c)[NQ]) {
   if (i > W - SFD_TURN - 1) return;
   if (i >= 2) Q.f5p = sfd_min(Q.f5p, sf_defer_colmin(Q, i - 1));
-  Q.P0 = sfd_min(Q.P0, Q.f5p + c0);
-  Q.P1 = sfd_min(Q.P1, Q.f5p + c1);
+#pragma unroll
+  for (int q = 0; q < NQ; q++) Q.P[q] = sfd_min(Q.P[q], Q.f5p + c[q]);
 }
 // rest of the sweep (if any), the last columns, the result
-__device__ __forceinline__ void sf_defer_finish(SfDeferred &Q, const int16_t *cgp, const int W, const int lane,
+template <int NQ>
+__device__ __forceinline__ void sf_defer_finish(SfDeferred<NQ> &Q, const int16_t *cgp, const int W, const int lane,
                                                 int32_t *__restrict__ out, int *__restrict__ ovf_cnt,
                                                 int *__restrict__ ovf_list) {
   for (int i = Q.row; i <= W - SFD_TURN - 1; i++) {
-    int c0, c1;
-    sf_defer_load(cgp, W, lane, i, c0, c1);
-    sf_defer_row(Q, W, i, c0, c1);
+    int c[NQ];
+    sf_defer_load<NQ>(cgp, W, lane, i, c);
+    sf_defer_row<NQ>(Q, W, i, c);
   }
   for (int jf = sfd_max(W - SFD_TURN - 1, 1); jf <= W; jf++) Q.f5p = sfd_min(Q.f5p, sf_defer_colmin(Q, jf));
   if (lane == 0) {
@@ -1075,6 +1090,7 @@ __device__ __forceinline__ void sf_defer_finish(SfDeferred &Q, const int16_t *cg
   }
   Q.row = 0;
 }
+
 
 // MG: the merged helper (narrow kernel, W < SF_HELP_MERGE_MAXW; the launcher picks the instantiation)
 template <int NG, int WT, bool MG = false>
@@ -1167,13 +1183,18 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
   const int split_d0 = can_split ? ((sfd_max(sfd_max(SFD_MAXLOOP + 6, 2 * (MAIN_LO - 1 + OFFs)), 2 * (W - OFFs - MAIN_HI)) + 1) & ~1) : 1 << 30;
 
   // deferred exterior sweep: wave 3 (the helper of the odd group) works on the previous fold's scratch
-  constexpr bool DEFER = SF_DEFER && (NG == 128);
-  const bool sweeper = DEFER && SF_WAVE_UNIFORM(tid >> 6) == 3;
+  // (not in the W = 200 instantiation: there the sweeper's state costs 56 B/lane of spills and the time it saves:
+  // 888 vs 892 k folds/s; the generic wide kernel gains 4-5 % — W = 136 / 160 / 256: 1.35 -> 1.43 M, 1.09 -> 1.15 M, 327 -> 342 k)
+  constexpr bool DEFER = SF_DEFER && (NG == 128 || (SF_DEFER_256 && WT != 200));
+  constexpr int NQ = NG / 64;  // columns per lane of the sweeper wave
+  const bool sweeper = DEFER && SF_WAVE_UNIFORM(tid >> 6) == (NG == 128 ? 3 : 7);  // a helper wave of the odd group
   const int n_split_steps = split_d0 < W ? (W - split_d0 + 1) / 2 : 0;
   const int defer_rows = n_split_steps > 0 ? (W - SFD_TURN - 1 + n_split_steps - 1) / n_split_steps : 0;  // rows per step
   const bool defer_on = DEFER && n_split_steps >= 8 && defer_rows <= 4;
-  SfDeferred Q;
-  Q.P0 = Q.P1 = SF_FAST_BIG * 2; Q.f5p = 0; Q.row = 0; Q.seq = -1; Q.over = 0;
+  SfDeferred<NQ> Q;
+#pragma unroll
+  for (int q = 0; q < NQ; q++) Q.P[q] = SF_FAST_BIG * 2;
+  Q.f5p = 0; Q.row = 0; Q.seq = -1; Q.over = 0;
   int cur_buf = 0;
   const int16_t *pend_cg = cg_pair;
 
@@ -1261,12 +1282,12 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
         uni = gt;
       }
       // deferred sweep of the previous fold: this step's rows are requested now, used after the wave's own work
-      int dc[4][2];
+      int dc[4][NQ];
       const bool sweep_now = defer_on && sweeper && split && Q.row > 0;
       if (sweep_now) {
 #pragma unroll
         for (int k = 0; k < 4; k++)
-          if (k < defer_rows) sf_defer_load(pend_cg, W, tid & 63, Q.row + k, dc[k][0], dc[k][1]);
+          if (k < defer_rows) sf_defer_load<NQ>(pend_cg, W, tid & 63, Q.row + k, dc[k]);
       }
       if (__ballot(valid)) {
         if (d0 < SF_FAST_TINY_D0) sf_fast_cell<true, WT, SF_SEC_ALL, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev);
@@ -1316,7 +1337,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
       if (sweep_now) {
 #pragma unroll
         for (int k = 0; k < 4; k++)
-          if (k < defer_rows) sf_defer_row(Q, W, Q.row + k, dc[k][0], dc[k][1]);
+          if (k < defer_rows) sf_defer_row<NQ>(Q, W, Q.row + k, dc[k]);
         Q.row += defer_rows;
       }
       // merged helper: wave 3 lists the next step's cells (the barriers of this step order the list before its readers)
@@ -1362,14 +1383,16 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
     // (sf_fast_exterior: lane = column, rows of c + ExtLoop stream from the scratch a few rows ahead)
     if (ovf) flag[0] = 1;
     // the previous fold's deferred sweep ends here at the latest
-    if (sweeper && Q.row > 0) sf_defer_finish(Q, pend_cg, W, tid & 63, out, ovf_cnt, ovf_list);
+    if (sweeper && Q.row > 0) sf_defer_finish<NQ>(Q, pend_cg, W, tid & 63, out, ovf_cnt, ovf_list);
     const bool want_trace_now = db_out && (seq % trace_stride) == 0;
     const bool last_fold = next_seq >= n;
     if (defer_on && !want_trace_now && !last_fold) {
       // hand this fold's scratch to the next fold's helper wave
       __syncthreads();  // every thread's overflow flag and scratch stores are in
       if (sweeper) {
-        Q.P0 = Q.P1 = SF_FAST_BIG * 2; Q.f5p = 0; Q.row = 1; Q.seq = seq; Q.over = flag[0];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) Q.P[q] = SF_FAST_BIG * 2;
+        Q.f5p = 0; Q.row = 1; Q.seq = seq; Q.over = flag[0];
       }
       pend_cg = X.cg;
       cur_buf ^= 1;

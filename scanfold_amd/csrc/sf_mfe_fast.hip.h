@@ -1038,6 +1038,12 @@ __device__ __forceinline__ void sf_fast_exterior(const SfFastCtx &X, const int W
 #ifndef SF_DEFER_256
 #define SF_DEFER_256 1  // the wide kernel defers too (four columns per lane)
 #endif
+#ifndef SF_DEFER_W200
+#define SF_DEFER_W200 1
+#endif
+#ifndef SF_DEFER_ROWS_256
+#define SF_DEFER_ROWS_256 2
+#endif
 template <int NQ>
 struct SfDeferred {
   int P[NQ], f5p;   // lane l: running minima of columns l+1, l+65, (l+129, l+193); f5[row-1]
@@ -1183,14 +1189,20 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
   const int split_d0 = can_split ? ((sfd_max(sfd_max(SFD_MAXLOOP + 6, 2 * (MAIN_LO - 1 + OFFs)), 2 * (W - OFFs - MAIN_HI)) + 1) & ~1) : 1 << 30;
 
   // deferred exterior sweep: wave 3 (the helper of the odd group) works on the previous fold's scratch
-  // (not in the W = 200 instantiation: there the sweeper's state costs 56 B/lane of spills and the time it saves:
-  // 888 vs 892 k folds/s; the generic wide kernel gains 4-5 % — W = 136 / 160 / 256: 1.35 -> 1.43 M, 1.09 -> 1.15 M, 327 -> 342 k)
-  constexpr bool DEFER = SF_DEFER && (NG == 128 || (SF_DEFER_256 && WT != 200));
+  // (the generic wide kernel gains 4-5 % — W = 136 / 160 / 256: 1.35 -> 1.43 M, 1.09 -> 1.15 M, 327 -> 342 k; in the
+  // W = 200 instantiation the sweeper's state spills ~50 B/lane: with four rows in flight it loses what it saves, with
+  // two — the rest of the sweep then runs at the end of the fold — it is +0.8 %, 894 -> 900 k)
+  constexpr bool DEFER = SF_DEFER && (NG == 128 || (SF_DEFER_256 && (WT != 200 || SF_DEFER_W200)));
   constexpr int NQ = NG / 64;  // columns per lane of the sweeper wave
   const bool sweeper = DEFER && SF_WAVE_UNIFORM(tid >> 6) == (NG == 128 ? 3 : 7);  // a helper wave of the odd group
   const int n_split_steps = split_d0 < W ? (W - split_d0 + 1) / 2 : 0;
-  const int defer_rows = n_split_steps > 0 ? (W - SFD_TURN - 1 + n_split_steps - 1) / n_split_steps : 0;  // rows per step
-  const bool defer_on = DEFER && n_split_steps >= 8 && defer_rows <= 4;
+  // rows per step: what finishes the sweep inside the split phase, but no more than DROWS in flight (their loads live
+  // in registers across the wave's own work: 4 x 2 columns in the narrow kernel, 2 x 4 in the wide one); what is
+  // left over is swept at the end of the fold (sf_defer_finish)
+  constexpr int DROWS = (NG == 128 || WT != 200) ? 4 : SF_DEFER_ROWS_256;
+  const int defer_need = n_split_steps > 0 ? (W - SFD_TURN - 1 + n_split_steps - 1) / n_split_steps : 0;
+  const int defer_rows = sfd_min(defer_need, DROWS);
+  const bool defer_on = DEFER && n_split_steps >= 8 && defer_need <= 4;
   SfDeferred<NQ> Q;
 #pragma unroll
   for (int q = 0; q < NQ; q++) Q.P[q] = SF_FAST_BIG * 2;
@@ -1282,11 +1294,11 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
         uni = gt;
       }
       // deferred sweep of the previous fold: this step's rows are requested now, used after the wave's own work
-      int dc[4][NQ];
+      int dc[DROWS][NQ];
       const bool sweep_now = defer_on && sweeper && split && Q.row > 0;
       if (sweep_now) {
 #pragma unroll
-        for (int k = 0; k < 4; k++)
+        for (int k = 0; k < DROWS; k++)
           if (k < defer_rows) sf_defer_load<NQ>(pend_cg, W, tid & 63, Q.row + k, dc[k]);
       }
       if (__ballot(valid)) {
@@ -1336,7 +1348,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
       }
       if (sweep_now) {
 #pragma unroll
-        for (int k = 0; k < 4; k++)
+        for (int k = 0; k < DROWS; k++)
           if (k < defer_rows) sf_defer_row<NQ>(Q, W, Q.row + k, dc[k]);
         Q.row += defer_rows;
       }

@@ -55,6 +55,7 @@ struct Ctx {
   int pf_kernel = 0;  // 0: LDS-resident kernel where it fits; 1: device-memory tables (SCANFOLD_PF_KERNEL=global)
   int pf_blocks_per_cu = 4;  // 256 VGPRs per thread: 2 waves per SIMD
   int pf_run_len = 0;        // > 0: forced run length of the shared-inside mode
+  int mfe_static = 0;        // SCANFOLD_MFE_STATIC=1: folds dealt to the workgroups in advance (measurement switch)
   int pf_share_inside = 1;   // sf_scan, step 1: consecutive native windows share their inside tables (SCANFOLD_PF_SHARE=0: off)
 } g;
 
@@ -319,7 +320,8 @@ int launch_mfe(const uint8_t *d_seqs, int n, int W, int32_t *d_out, hipStream_t 
     if (rc) return rc;
     if ((rc = prof.begin(st))) return rc;
     sf_fast_launch(grid, threads, lds, st, d_seqs, n, W, (const SfDevParams *)g.dP, (const SfFastParams *)g.dF,
-                     (int16_t *)g.fast_scratch.p, d_out, d_cnt, d_list, trace_stride, d_db, (int *)g.status.p, d_work);
+                     (int16_t *)g.fast_scratch.p, d_out, d_cnt, d_list, trace_stride, d_db, (int *)g.status.p,
+                     g.mfe_static ? (int *)nullptr : d_work);
     HIPCHK(hipGetLastError());
     if ((rc = prof.end(st))) return rc;
     // folds that left the int16 range are redone exactly
@@ -398,6 +400,7 @@ int sf_init(int device_ordinal) {
   if (const char *ps = getenv("SCANFOLD_PF_SHARE")) g.pf_share_inside = atoi(ps) != 0;
   if (const char *pr = getenv("SCANFOLD_PF_RUN_LEN")) g.pf_run_len = atoi(pr);
   if (const char *pb = getenv("SCANFOLD_PF_BLOCKS_PER_CU")) g.pf_blocks_per_cu = atoi(pb) > 0 ? atoi(pb) : 4;
+  if (const char *ms = getenv("SCANFOLD_MFE_STATIC")) g.mfe_static = atoi(ms) != 0;
   const char *ff = getenv("SCANFOLD_FORCE_FULL");
   g.force_full = (ff && ff[0] == '1');
   g.init = true;

@@ -1224,7 +1224,11 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
     __syncthreads();
     for (int x = tid; x < W; x += NT) S[x + 1] = sf_encode_nt(src[x]);
     int fetched = 0;
-    if (tid == 0) { S[0] = 0; S[W + 1] = 0; flag[0] = 0; fetched = (int)gridDim.x + atomicAdd(work_ctr, 1); }
+    if (tid == 0) {
+      S[0] = 0; S[W + 1] = 0; flag[0] = 0;
+      // (work_ctr == nullptr: the static deal of rounds 1-2, kept as a measurement switch: SCANFOLD_MFE_STATIC=1)
+      fetched = work_ctr ? (int)gridDim.x + atomicAdd(work_ctr, 1) : seq + (int)gridDim.x;
+    }
     __syncthreads();
     int next_seq = n;  // (set in the third step; W >= 16 has at least five)
     int ovf = 0;

@@ -697,8 +697,7 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
 // round trips (the generic __shfl_xor butterfly lowers to ds_bpermute, ~6 dependent LDS-crossbar trips).
 __device__ __forceinline__ int sf_wave_min(int v) {
 #ifdef SF_EMUL
-  for (int m = 32; m >= 1; m >>= 1) v = sfd_min(v, __shfl_xor(v, m));
-  return v;
+  return sfemul_wave_min(v);
 #else
   v = sfd_min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
   v = sfd_min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
@@ -1026,17 +1025,21 @@ __device__ __forceinline__ void sf_fast_exterior(const SfFastCtx &X, const int W
   }
 }
 
-// Deferred exterior sweep.  A fold whose structure is not wanted does not run its exterior sweep at
-// its own end — one wave working for ~50 k cycles while the fold's other three wait at the next barrier, 8 % of a
-// fold's residency — but hands its c + ExtLoop scratch (the workgroup owns two, used alternately) to the NEXT fold:
-// the helper wave of the odd diagonal group sweeps SF_DEFER_ROWS rows of it in every step of the long-diagonal
-// phase, in the slack it has there (it only computes the special / bulge / 1xn minima of its step).  The row loads
-// are issued before that work and consumed after it.  State: the two column minima, f5 of the previous row.
+// Trailing exterior sweep.  A fold whose structure is not wanted does not run the 5' -> 3' sweep at its end (one wave
+// working for ~50 k cycles while the other three wait: 8 % of a fold's residency) and does not hand its scratch to the
+// next fold either (round 2: two scratch tables per workgroup, 28 MB for the grid against 32 MB of L2, 65 GB of
+// L2 <-> fabric traffic per cfg3 launch).  It runs the SAME recurrence from the other end,
+//   f3[i] = min(f3[i+1], min_j c[i,j] + ExtLoop(i,j) + f3[j+1]),   f3[k > W-4] = 0,   MFE = f3[1] (= f5[W]),
+// whose rows are needed in DESCENDING order — and row i of the scratch is complete as soon as diagonal W-i is, so the
+// sweep trails the fill inside the same fold: the helper wave of the odd diagonal group sweeps up to SF_DEFER_ROWS rows in
+// every step of the long-diagonal phase, in the slack it has there (loads issued before its own work, consumed after
+// it), and only the rows the last step completes are left for the end of the fold.  One scratch per workgroup.
+// State: lane l holds f3[j+1] of its columns j = l+1, l+65, ...; f3 of the row above the next one.
 #ifndef SF_DEFER
 #define SF_DEFER 1
 #endif
 #ifndef SF_DEFER_256
-#define SF_DEFER_256 1  // the wide kernel defers too (four columns per lane)
+#define SF_DEFER_256 1  // the wide kernel trails too (four columns per lane)
 #endif
 #ifndef SF_DEFER_W200
 #define SF_DEFER_W200 1
@@ -1045,56 +1048,55 @@ __device__ __forceinline__ void sf_fast_exterior(const SfFastCtx &X, const int W
 #define SF_DEFER_ROWS_256 2
 #endif
 template <int NQ>
-struct SfDeferred {
-  int P[NQ], f5p;   // lane l: running minima of columns l+1, l+65, (l+129, l+193); f5[row-1]
-  int row;          // next row to sweep (1-based); 0 = nothing pending
-  int seq, over;    // the pending fold's index and its int16-overflow flag
+struct SfTrail {
+  int F[NQ];   // lane l: f3[j+1] for the columns j = l+1+64q (0 until row j+1 has been swept)
+  int f3n;     // f3[row+1]
+  int row;     // next row to sweep (descending); 0 = done / nothing pending
 };
 template <int NQ>
-__device__ __forceinline__ void sf_defer_load(const int16_t *cgp, const int W, const int lane, const int i, int (&c)[NQ]) {
+__device__ __forceinline__ void sf_trail_load(const int16_t *cgp, const int W, const int lane, const int i, int (&c)[NQ]) {
 #pragma unroll
   for (int q = 0; q < NQ; q++) {
     const int j = lane + 1 + 64 * q;
-    c[q] = (i <= W - SFD_TURN - 1 && j <= W && i + SFD_TURN + 1 <= j) ? (int)cgp[SF_CGIDX(i, j)] : SF_INF16;
+    c[q] = (i >= 1 && j <= W && i + SFD_TURN + 1 <= j) ? (int)cgp[SF_CGIDX(i, j)] : SF_INF16;
   }
 }
+// Row i (wave-uniform; rows below 1 do not exist).  (The rows of a step do not depend on each other — a row reads f3[j+1]
+// for j >= i+4 only — but computing their wave minima side by side changed nothing: the sweep costs issue slots, not
+// latency.  Sweeping fewer rows per step in the first half of the split phase and more in the second, where the stamps
+// show the helper waves waiting longer, measured 0.5-2 % slower.  profiles/r03/mfe_trailing_sweep.txt)
 template <int NQ>
-__device__ __forceinline__ int sf_defer_colmin(const SfDeferred<NQ> &Q, const int jf) {  // P of column jf from its lane
-  const int l = (jf - 1) & 63, h = (jf - 1) >> 6;
-  int v = SF_LANE_READ(Q.P[0], l);
+__device__ __forceinline__ void sf_trail_row(SfTrail<NQ> &T, const int lane, const int i, const int (&c)[NQ]) {
+  if (i < 1) return;
+  int m = c[0] + T.F[0];
 #pragma unroll
-  for (int q = 1; q < NQ; q++) {
-    const int vq = SF_LANE_READ(Q.P[q], l);
-    v = h == q ? vq : v;
+  for (int q = 1; q < NQ; q++) m = sfd_min(m, c[q] + T.F[q]);
+  T.f3n = sfd_min(T.f3n, sf_wave_min(m));  // f3[i] ...
+  if (i >= 2) {                            // ... which is f3[j+1] of column j = i-1
+    const int l = (i - 2) & 63, h = (i - 2) >> 6;
+#pragma unroll
+    for (int q = 0; q < NQ; q++) T.F[q] = (lane == l && h == q) ? T.f3n : T.F[q];
   }
-  return v;
 }
-template <int NQ>
-__device__ __forceinline__ void sf_defer_row(SfDeferred<NQ> &Q, const int W, const int i, const int (&c)[NQ]) {
-  if (i > W - SFD_TURN - 1) return;
-  if (i >= 2) Q.f5p = sfd_min(Q.f5p, sf_defer_colmin(Q, i - 1));
+template <int NQ, int NR>
+__device__ __forceinline__ void sf_trail_rows(SfTrail<NQ> &T, const int lane, const int nrows, const int (&c)[NR][NQ]) {
 #pragma unroll
-  for (int q = 0; q < NQ; q++) Q.P[q] = sfd_min(Q.P[q], Q.f5p + c[q]);
+  for (int k = 0; k < NR; k++)
+    if (k < nrows) sf_trail_row<NQ>(T, lane, T.row - k, c[k]);
+  T.row -= nrows;
 }
-// rest of the sweep (if any), the last columns, the result
+// the energy / overflow record of a fold whose sweep is complete
 template <int NQ>
-__device__ __forceinline__ void sf_defer_finish(SfDeferred<NQ> &Q, const int16_t *cgp, const int W, const int lane,
+__device__ __forceinline__ void sf_trail_result(const SfTrail<NQ> &T, const int lane, const int seq, const int over,
                                                 int32_t *__restrict__ out, int *__restrict__ ovf_cnt,
                                                 int *__restrict__ ovf_list) {
-  for (int i = Q.row; i <= W - SFD_TURN - 1; i++) {
-    int c[NQ];
-    sf_defer_load<NQ>(cgp, W, lane, i, c);
-    sf_defer_row<NQ>(Q, W, i, c);
-  }
-  for (int jf = sfd_max(W - SFD_TURN - 1, 1); jf <= W; jf++) Q.f5p = sfd_min(Q.f5p, sf_defer_colmin(Q, jf));
   if (lane == 0) {
-    out[Q.seq] = Q.f5p;
-    if (Q.over || Q.f5p < SF_FAST_OVF) {
+    out[seq] = T.f3n;
+    if (over || T.f3n < SF_FAST_OVF) {
       const int k = atomicAdd(ovf_cnt, 1);
-      ovf_list[k] = Q.seq;
+      ovf_list[k] = seq;
     }
   }
-  Q.row = 0;
 }
 
 
@@ -1145,8 +1147,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
   int16_t *tExt = (int16_t *)(smem + Lo.off_ci + (((W + 1) * 4 + 3) & ~3));
 
   const int tid = threadIdx.x;
-  int16_t *const cg_pair = cg_all + (size_t)blockIdx.x * 2 * SF_CG_ENTRIES(W);  // two scratch tables, used alternately
-  X.cg = cg_pair;                                                                // c + ExtLoop by (row i, column j), triangular
+  X.cg = cg_all + (size_t)blockIdx.x * SF_CG_ENTRIES(W);  // c + ExtLoop by (row i, column j), triangular
   // parameter tables -> LDS, once per workgroup
   for (int x = tid; x < 175; x += NT) {
     tab[x] = F->mm23[x];
@@ -1188,27 +1189,26 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
   const bool can_split = SF_FAST_SPLIT && ((NG == 128 && W >= 64) || (NG == 256 && SF_FAST_SPLIT_256));
   const int split_d0 = can_split ? ((sfd_max(sfd_max(SFD_MAXLOOP + 6, 2 * (MAIN_LO - 1 + OFFs)), 2 * (W - OFFs - MAIN_HI)) + 1) & ~1) : 1 << 30;
 
-  // deferred exterior sweep: wave 3 (the helper of the odd group) works on the previous fold's scratch
-  // (the generic wide kernel gains 4-5 % — W = 136 / 160 / 256: 1.35 -> 1.43 M, 1.09 -> 1.15 M, 327 -> 342 k; in the
-  // W = 200 instantiation the sweeper's state spills ~50 B/lane: with four rows in flight it loses what it saves, with
-  // two — the rest of the sweep then runs at the end of the fold — it is +0.8 %, 894 -> 900 k)
+  // trailing exterior sweep (see SfTrail): wave 3 (the helper of the odd group) sweeps the rows of this fold's scratch
+  // that are already complete
+  // (round 2, with the sweep deferred to the next fold: the generic wide kernel gained 4-5 % — W = 136 / 160 / 256:
+  // 1.35 -> 1.43 M, 1.09 -> 1.15 M, 327 -> 342 k; in the W = 200 instantiation the sweeper's state spills ~50 B/lane:
+  // with four rows in flight it loses what it saves, with two it is +0.8 %, 894 -> 900 k)
   constexpr bool DEFER = SF_DEFER && (NG == 128 || (SF_DEFER_256 && (WT != 200 || SF_DEFER_W200)));
   constexpr int NQ = NG / 64;  // columns per lane of the sweeper wave
   const bool sweeper = DEFER && SF_WAVE_UNIFORM(tid >> 6) == (NG == 128 ? 3 : 7);  // a helper wave of the odd group
   const int n_split_steps = split_d0 < W ? (W - split_d0 + 1) / 2 : 0;
   // rows per step: what finishes the sweep inside the split phase, but no more than DROWS in flight (their loads live
   // in registers across the wave's own work: 4 x 2 columns in the narrow kernel, 2 x 4 in the wide one); what is
-  // left over is swept at the end of the fold (sf_defer_finish)
+  // left over is swept at the end of the fold
   constexpr int DROWS = (NG == 128 || WT != 200) ? 4 : SF_DEFER_ROWS_256;
   const int defer_need = n_split_steps > 0 ? (W - SFD_TURN - 1 + n_split_steps - 1) / n_split_steps : 0;
   const int defer_rows = sfd_min(defer_need, DROWS);
   const bool defer_on = DEFER && n_split_steps >= 8 && defer_need <= 4;
-  SfDeferred<NQ> Q;
+  SfTrail<NQ> T;
 #pragma unroll
-  for (int q = 0; q < NQ; q++) Q.P[q] = SF_FAST_BIG * 2;
-  Q.f5p = 0; Q.row = 0; Q.seq = -1; Q.over = 0;
-  int cur_buf = 0;
-  const int16_t *pend_cg = cg_pair;
+  for (int q = 0; q < NQ; q++) T.F[q] = 0;
+  T.f3n = 0; T.row = 0;
 
   // Folds are handed out dynamically: a workgroup's first fold is its block index, every further one comes from a
   // device-wide counter (zeroed by the host; grid size + its value).  The folds cost the same number of instructions, but
@@ -1220,7 +1220,6 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
   int seq = blockIdx.x;
   while (seq < n) {
     const uint8_t *src = seqs + (size_t)seq * W;
-    X.cg = cg_pair + (size_t)cur_buf * SF_CG_ENTRIES(W);
     __syncthreads();
     for (int x = tid; x < W; x += NT) S[x + 1] = sf_encode_nt(src[x]);
     int fetched = 0;
@@ -1231,6 +1230,13 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
     }
     __syncthreads();
     int next_seq = n;  // (set in the third step; W >= 16 has at least five)
+    // a fold whose structure is wanted keeps the 5' -> 3' sweep at its end (the traceback reads f5[])
+    const bool trail_this = defer_on && !(db_out && (seq % trace_stride) == 0);
+    if (sweeper) {
+#pragma unroll
+      for (int q = 0; q < NQ; q++) T.F[q] = 0;
+      T.f3n = 0; T.row = trail_this ? W - SFD_TURN - 1 : 0;
+    }
     int ovf = 0;
     uint32_t H[14];  // packed int16 pairs, see HGET/HSET
     int dprev = SF_INF16;   // multiloop split of this thread's previous cell (diagonals 2, 3: none)
@@ -1297,13 +1303,15 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
         SF_WAVE_SYNC();
         uni = gt;
       }
-      // deferred sweep of the previous fold: this step's rows are requested now, used after the wave's own work
+      // trailing sweep: the rows i >= W-d0+1 are complete (diagonals < d0 are); this step's rows are requested now, used
+      // after the wave's own work
       int dc[DROWS][NQ];
-      const bool sweep_now = defer_on && sweeper && split && Q.row > 0;
+      const bool sweep_now = defer_on && sweeper && split && T.row > 0;
+      const int sweep_rows = sweep_now ? sfd_max(sfd_min(defer_rows, T.row - (W - d0)), 0) : 0;
       if (sweep_now) {
 #pragma unroll
         for (int k = 0; k < DROWS; k++)
-          if (k < defer_rows) sf_defer_load<NQ>(pend_cg, W, tid & 63, Q.row + k, dc[k]);
+          if (k < sweep_rows) sf_trail_load<NQ>(X.cg, W, tid & 63, T.row - k, dc[k]);
       }
       if (__ballot(valid)) {
         if (d0 < SF_FAST_TINY_D0) sf_fast_cell<true, WT, SF_SEC_ALL, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev);
@@ -1350,12 +1358,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
           }
         }
       }
-      if (sweep_now) {
-#pragma unroll
-        for (int k = 0; k < DROWS; k++)
-          if (k < defer_rows) sf_defer_row<NQ>(Q, W, Q.row + k, dc[k]);
-        Q.row += defer_rows;
-      }
+      if (sweep_now && sweep_rows > 0) sf_trail_rows<NQ, DROWS>(T, tid & 63, sweep_rows, dc);
       // merged helper: wave 3 lists the next step's cells (the barriers of this step order the list before its readers)
       if (MERGE && grp == 1 && tg >= 64 && d0 + 2 >= split_d0 && d0 + 2 < W) build_list(d0 + 2);
       if (split) {
@@ -1398,20 +1401,19 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
     // ---- exterior loop f5[j] = min(f5[j-1], min_i f5[i-1] + c[i,j] + ExtLoop(i,j)) : wave 0 only ----
     // (sf_fast_exterior: lane = column, rows of c + ExtLoop stream from the scratch a few rows ahead)
     if (ovf) flag[0] = 1;
-    // the previous fold's deferred sweep ends here at the latest
-    if (sweeper && Q.row > 0) sf_defer_finish<NQ>(Q, pend_cg, W, tid & 63, out, ovf_cnt, ovf_list);
-    const bool want_trace_now = db_out && (seq % trace_stride) == 0;
-    const bool last_fold = next_seq >= n;
-    if (defer_on && !want_trace_now && !last_fold) {
-      // hand this fold's scratch to the next fold's helper wave
-      __syncthreads();  // every thread's overflow flag and scratch stores are in
+    if (trail_this) {
+      // the rows the last steps completed, the energy / overflow record
+      // (issuing these rows' loads before the barrier measured 3 % slower at W = 120)
+      __syncthreads();  // every thread's overflow flag is in
       if (sweeper) {
+        while (T.row >= 1) {
+          int tc[4][NQ];
 #pragma unroll
-        for (int q = 0; q < NQ; q++) Q.P[q] = SF_FAST_BIG * 2;
-        Q.f5p = 0; Q.row = 1; Q.seq = seq; Q.over = flag[0];
+          for (int k = 0; k < 4; k++) sf_trail_load<NQ>(X.cg, W, tid & 63, T.row - k, tc[k]);
+          sf_trail_rows<NQ, 4>(T, tid & 63, sfd_min(4, T.row), tc);
+        }
+        sf_trail_result<NQ>(T, tid & 63, seq, flag[0], out, ovf_cnt, ovf_list);
       }
-      pend_cg = X.cg;
-      cur_buf ^= 1;
     } else {
     for (int x = tid; x < 200; x += NT) tExt[x] = F->mmExt[x];
     __syncthreads();
@@ -1460,7 +1462,7 @@ static inline void sf_fast_geometry(int W, int n_cu, int n, int *grid, int *thre
   *grid = (int)gsz;
   *threads = nt;
   *lds = (size_t)L.total;
-  *scratch = (size_t)gsz * 2 * SF_CG_ENTRIES(W) * sizeof(int16_t);  // two per workgroup (deferred exterior sweep)
+  *scratch = (size_t)gsz * SF_CG_ENTRIES(W) * sizeof(int16_t);
 }
 
 // W = 120 is ScanFold's default window (ScanFold-Scan.py:37) and W = 200 is BASELINE config 5: they get

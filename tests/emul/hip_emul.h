@@ -144,6 +144,20 @@ inline unsigned long long __ballot(int pred) {
   sfemul::wave_barrier();
   return m;
 }
+// minimum over the lanes of a wave in ONE exchange round (the kernels' DPP reduction, sf_wave_min)
+inline int sfemul_wave_min(int v) {
+  sfemul::Block *b = sfemul::g_blk;
+  int t = sfemul::tid();
+  b->exch[t] = (uint64_t)(uint32_t)v;
+  sfemul::wave_barrier();
+  int base = (t / 64) * 64, m = v;
+  for (int l = 0; l < 64 && base + l < (int)b->nthreads; l++) {
+    const int x = (int)(uint32_t)b->exch[base + l];
+    if (x < m) m = x;
+  }
+  sfemul::wave_barrier();
+  return m;
+}
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
 template <typename T>

@@ -320,7 +320,9 @@ def get_engine(device=None):
     global _engine
     if _engine is None:
         if device is None:
-            device = int(os.environ.get("LOCAL_RANK", "0"))
-        _engine = Engine(device=device)
+            # SCANFOLD_DEVICE: several ranks on one GPU (the 2-rank test on a 1-GPU box); default: the rank's own GPU
+            device = int(os.environ.get("SCANFOLD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        # SCANFOLD_LIB_PATH: another build of the same C ABI (build variants; tests/emul's CPU build in the no-GPU suite)
+        _engine = Engine(device=device, lib_path=os.environ.get("SCANFOLD_LIB_PATH", LIB_PATH))
         _params.warn_if_reconstructed(_engine.params)  # the shipped table is not ViennaRNA's: say so once
     return _engine

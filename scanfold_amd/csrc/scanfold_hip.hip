@@ -86,8 +86,17 @@ int block_threads(int W) {
   return t < 64 ? 64 : t;
 }
 
+// Every entry point that touches the device: the library must be initialised, and HIP's current device is PER THREAD —
+// hipSetDevice in sf_init binds only the thread that called it, so a caller's helper thread (scan.py runs the engine
+// from one) would otherwise allocate and copy on device 0 while g.stream and the kernels belong to g.dev.
+#define SF_ENTER()                          \
+  do {                                      \
+    if (!g.init) return SF_ERR_NOT_INIT;    \
+    HIPCHK(hipSetDevice(g.dev));            \
+  } while (0)
+
 int check_ready() {
-  if (!g.init) return SF_ERR_NOT_INIT;
+  SF_ENTER();
   if (!g.have_params) return SF_ERR_NO_PARAMS;
   return SF_OK;
 }
@@ -433,14 +442,14 @@ int sf_shutdown(void) {
 }
 
 int sf_device_name(char *buf, size_t n) {
-  if (!g.init) return SF_ERR_NOT_INIT;
+  SF_ENTER();
   if (!buf || n == 0) return SF_ERR_BAD_ARG;
   snprintf(buf, n, "%s", g.dev_name.c_str());
   return SF_OK;
 }
 
 int sf_params_load(const void *blob, size_t nbytes, double temperature_c) {
-  if (!g.init) return SF_ERR_NOT_INIT;
+  SF_ENTER();
   if (!blob || nbytes != sizeof(sf_params_blob)) return SF_ERR_BAD_PARAMS;
   static sf_params_blob P;
   memcpy(&P, blob, sizeof P);
@@ -453,7 +462,7 @@ int sf_params_load(const void *blob, size_t nbytes, double temperature_c) {
   D.max_pair_dist = g.max_bp_span > 0 ? g.max_bp_span - 1 : 0x7fffffff;
   sf_fast_build_params(D, F);
   g.fast_ok = F.fast_ok;
-  HIPCHK(hipStreamSynchronize(g.stream));
+  HIPCHK(hipDeviceSynchronize());  // *_dev work queued on the callers' own streams still reads the old tables
   HIPCHK(hipMemcpy(g.dP, &D, sizeof D, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(g.dX, &X, sizeof X, hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(g.dF, &F, sizeof F, hipMemcpyHostToDevice));
@@ -592,7 +601,7 @@ static int launch_shuffle(const uint8_t *d_tr, int L, int W, int step, int win_b
 
 int sf_shuffle_windows(const uint8_t *transcript, int L, int W, int step, int win_begin, int n_win, int r, int kind,
                        uint64_t seed, uint8_t *seqs_out) {
-  if (!g.init) return SF_ERR_NOT_INIT;
+  SF_ENTER();
   int rc = check_scan_args(L, W, step, win_begin, n_win, r, kind);
   if (rc) return rc;
   if (!transcript || (n_win > 0 && !seqs_out)) return SF_ERR_BAD_ARG;
@@ -692,7 +701,7 @@ static TabOut tab_out_views(int64_t n) {
 
 int sf_tabulate_pairs(const char *structures, int row_stride, int structures_on_device, int n_win, int W,
                       const int32_t *starts, const double *z, const double *mfe, const double *ed, int64_t *n_groups) {
-  if (!g.init) return SF_ERR_NOT_INIT;
+  SF_ENTER();
   g.tab_groups = -1;
   if (n_win < 1 || W < 1 || W > SF_MAX_W || row_stride < W || !structures || !starts || !z || !mfe || !ed || !n_groups)
     return SF_ERR_BAD_ARG;
@@ -755,7 +764,7 @@ int sf_tabulate_pairs(const char *structures, int row_stride, int structures_on_
 
 int sf_tabulate_fetch(int32_t *group_k, int32_t *group_j, int32_t *group_windows, int32_t *group_first_window,
                       double *group_sum_z, double *group_sum_mfe, double *group_sum_ed) {
-  if (!g.init) return SF_ERR_NOT_INIT;
+  SF_ENTER();
   if (g.tab_groups < 0) return SF_ERR_BAD_ARG;  // no finished sf_tabulate_pairs
   const int64_t n = g.tab_groups;
   if (n == 0) return SF_OK;
@@ -773,12 +782,12 @@ int sf_tabulate_fetch(int32_t *group_k, int32_t *group_j, int32_t *group_windows
 }
 
 int sf_last_status(void) {
-  if (!g.init) return SF_ERR_NOT_INIT;
+  SF_ENTER();
   return read_status(nullptr, true);
 }
 
 int sf_set_max_bp_span(int span) {
-  if (!g.init) return SF_ERR_NOT_INIT;
+  SF_ENTER();
   g.max_bp_span = span > 0 ? span : 0;
   if (g.have_params) {  // patch the field of the resident model
     const int32_t md = g.max_bp_span > 0 ? g.max_bp_span - 1 : 0x7fffffff;
@@ -789,7 +798,7 @@ int sf_set_max_bp_span(int span) {
 }
 
 int sf_set_kernel_mode(int mode) {
-  if (!g.init) return SF_ERR_NOT_INIT;
+  SF_ENTER();
   if (mode < 0 || mode > 1) return SF_ERR_BAD_ARG;
   g.force_full = (mode == 1);
   return SF_OK;
@@ -797,7 +806,7 @@ int sf_set_kernel_mode(int mode) {
 
 
 int sf_prof_reset(void) {
-  if (!g.init) return SF_ERR_NOT_INIT;
+  SF_ENTER();
   HIPCHK(hipDeviceSynchronize());
   for (auto &e : g.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
   g.ev.clear();
@@ -809,7 +818,7 @@ int sf_prof_reset(void) {
 }
 
 int sf_prof_get(double *ms, int64_t *launches, int64_t *folds) {
-  if (!g.init) return SF_ERR_NOT_INIT;
+  SF_ENTER();
   HIPCHK(hipDeviceSynchronize());
   ProfPair::prof_drain();
   if (ms) *ms = g.prof_ms;
@@ -819,7 +828,7 @@ int sf_prof_get(double *ms, int64_t *launches, int64_t *folds) {
 }
 
 int sf_prof_stop(void) {
-  if (!g.init) return SF_ERR_NOT_INIT;
+  SF_ENTER();
   g.prof_on = false;
   return SF_OK;
 }

@@ -37,15 +37,20 @@ __global__ void sf_tab_partner_kernel(const char *__restrict__ structs, const in
     const char ch = s[p];
     int q = -1;
     if (ch == '(') {
-      stack[depth * 64 + lane] = (int16_t)p;
+      // the stack holds W/2 + 1 entries per lane: a row with more open brackets than that cannot balance
+      // (rows come from a user's TSV in the Fold stage)
+      if (depth > W / 2) bad = 1;
+      else stack[depth * 64 + lane] = (int16_t)p;
       depth++;
     } else if (ch == ')') {
       if (depth == 0) {
         bad = 1;
       } else {
         depth--;
-        q = stack[depth * 64 + lane];
-        out[q] = (int16_t)p;
+        if (depth <= W / 2) {
+          q = stack[depth * 64 + lane];
+          out[q] = (int16_t)p;
+        }
       }
     }
     out[p] = (int16_t)q;

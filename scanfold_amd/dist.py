@@ -8,6 +8,11 @@ backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.
 
 Record layout (bytes, per window): int32 energies[r+1] | char structure[W+1] | char centroid[W+1] |
 pad to 8 | float64 ens_div | float64 ens_dG.
+
+Two users: bench.py keeps everything device-resident and gathers those records (pack_records on the device,
+gather_records); the command lines (scan.py, scanfold.py --gpus N) let every rank turn ITS windows into TSV rows —
+z-scores, p-scores and formatting are per window, so the host work shards as well as the folds do — and gather the
+rows (gather_rows): still one collective per record, and rank 0 only writes.
 """
 import numpy as np
 
@@ -85,6 +90,57 @@ def merge_shards(gathered, n_items, world, W, r):
         parts.append(g[rank * per: rank * per + (hi - lo)])
     rec = np.concatenate(parts, axis=0) if parts else g[:0]
     return unpack_records(rec, W, r, n_items)
+
+
+def row_slot_width(W):
+    """Bytes reserved per TSV row in the row gather: i, j, T, dG, z, p, ED (< 96 characters together with the tabs and
+    the gc_content column of the ScanFold.py flavour) + sequence, structure, centroid."""
+    return 3 * W + 128
+
+
+def pack_rows(rows, n_pad, width):
+    """list of row strings -> uint8 numpy [n_pad, width], zero-padded (a row never contains a zero byte)."""
+    enc = [row.encode("ascii") for row in rows]
+    if enc and max(map(len, enc)) > width:
+        raise ValueError("a TSV row of %d bytes does not fit the %d-byte gather slot" % (max(map(len, enc)), width))
+    blob = b"".join(b.ljust(width, b"\0") for b in enc) + bytes((n_pad - len(enc)) * width)
+    return np.frombuffer(blob, dtype=np.uint8).reshape(n_pad, width).copy()
+
+
+def unpack_rows(buf, n):
+    """uint8 [>= n, width] -> list of n row strings (every row ends with its newline)."""
+    text = np.ascontiguousarray(buf[:n]).tobytes().replace(b"\0", b"").decode("ascii")
+    rows = text.splitlines(keepends=True)
+    if len(rows) != n:
+        raise ValueError("row gather: %d rows unpacked, %d expected" % (len(rows), n))
+    return rows
+
+
+def gather_rows(rows, n_items, rank, world, W, device=None, want=True):
+    """Every rank hands in the TSV rows of ITS window range (formatted where they were computed); ONE all-gather of
+    fixed-size row slots returns all n_items rows in window order (want=False: None — a rank that does not write).
+    `device`: where the collective's tensors live (the rank's GPU under nccl/RCCL, None = host under gloo)."""
+    import torch
+    import torch.distributed as dist
+    lo, hi = shard_range(n_items, rank, world)
+    if len(rows) != hi - lo:
+        raise ValueError("rank %d formatted %d rows for the range [%d, %d)" % (rank, len(rows), lo, hi))
+    if world == 1:
+        return list(rows)
+    per, width = shard_size(n_items, world), row_slot_width(W)
+    local = torch.from_numpy(pack_rows(rows, per, width))
+    if device is not None:
+        local = local.to(device)
+    out = torch.empty((world * per, width), dtype=torch.uint8, device=local.device)
+    dist.all_gather_into_tensor(out, local.contiguous())
+    if not want:
+        return None
+    g = out.cpu().numpy()
+    merged = []
+    for rk in range(world):
+        a, b = shard_range(n_items, rk, world)
+        merged.extend(unpack_rows(g[rk * per: rk * per + (b - a)], b - a))
+    return merged
 
 
 def scan_sharded(produce, n_win, W, r, rank, world, xp):

@@ -14,7 +14,7 @@ floating-point sums, means and the SumZ/#TotalWindows quotient are the reference
 nucleotides one at a time, over precomputed neighbour lists.  Output files are byte-identical to the reference's
 (tests/golden/fold_*: produced by running the reference script, see tests/golden/make_golden_fold.py).
 
-`-c 0` (competition allowed: DP files instead of CT files) is not implemented.
+`-c 0` (competition allowed, :1022-1038) writes the DP files of every nucleotide's best partner and best_bps_test.bp.
 """
 import argparse
 import os
@@ -290,8 +290,7 @@ def compete(tab, res, log_path=None):
     fin_i = np.empty(n, dtype=np.int64)
     fin_j = np.empty(n, dtype=np.int64)
     fin_z = np.empty(n, dtype=np.float64)
-    lines = ["\ni\tbp(i)\tbp(j)\tavgMFE\tavgZ\tavgED\t*Indicates most favorable bp has more favorable partner or is "
-             "more likely to be unpaired (competing coordinates are reported)\n"]
+    lines = [COMPETE_HEADER]
     r_mfe, r_z, r_ed = _round2(res.best_mean_mfe), _round2(res.best_mean_z), _round2(res.best_mean_ed)
     r_tw = _round2(twz)
     cache = {}
@@ -347,13 +346,28 @@ def write_ct(tab, res, path, filt, header_name=None):
         f.write("".join(out))
 
 
-def write_bp(tab, res, path, ident):
-    """write_bp (ScanFold-Fold.py:399-451): IGV arc track, one line per nucleotide, colour class by mean z-score."""
+def write_dp(res, path, filt, minz):
+    """write_dp (ScanFold-Fold.py:380-394; ScanFoldFunctions.py:564-578): IGV "dot plot" lines of the BEST partner of every
+    nucleotide whose mean z-score is below the filter — i, j, (-1/minz * z) / minz — the competition-allowed mode's output
+    (the three branches of the reference print the same three numbers: an unpaired nucleotide has j == k)."""
+    out = ["%d\t%d\t%f\n" % (k, j, float((-1 / minz) * z) / minz)
+           for k, j, z in zip(res.coords.tolist(), res.best_j.tolist(), res.best_mean_z.tolist()) if z < filt]
+    with open(path, "w") as f:
+        f.write("".join(out))
+
+
+def write_bp(tab, res, path, ident, best=False):
+    """write_bp (ScanFold-Fold.py:399-451): IGV arc track, one line per nucleotide, colour class by mean z-score.
+    best: the track of the best partners before competition (`best_bps`, written by -c 0) instead of the final ones."""
     minz = min(tab.window_z.tolist())
+    if best:
+        fin_i, fin_j, fin_z = res.coords, res.best_j, res.best_mean_z
+    else:
+        fin_i, fin_j, fin_z = res.fin_i, res.fin_j, res.fin_z
     out = ["color:\t55\t129\t255\tLess than -2 %s\n" % str(minz), "color:\t89\t222\t111\t-1 to -2\n",
            "color:\t236\t236\t136\t0 to -1\n", "color:\t199\t199\t199\t0\n", "color:\t228\t228\t228\t0 to 1\n",
            "color:\t243\t243\t243\t1 to 2\n", "color:\t247\t247\t247\tGreater than 2\n"]
-    z = res.fin_z
+    z = fin_z
     score = np.full(len(z), 6)
     score[z <= 2] = 5
     score[z <= 1] = 4
@@ -362,7 +376,7 @@ def write_bp(tab, res, path, ident):
     score[z < -1] = 1
     score[z < -2] = 0
     for t in range(len(z)):
-        a, b = int(res.fin_i[t]), int(res.fin_j[t])
+        a, b = int(fin_i[t]), int(fin_j[t])
         if a == b:
             a = int(res.coords[t])
         out.append("%s\t%d\t%d\t%d\t%d\t%d\n" % (ident, a, a, b, b, score[t]))
@@ -370,15 +384,31 @@ def write_bp(tab, res, path, ident):
         f.write("".join(out))
 
 
-def fold(table, prefix, filt=-2, bp_path="final_partners_test.bp", write_log=True, engine=None):
+COMPETE_HEADER = ("\ni\tbp(i)\tbp(j)\tavgMFE\tavgZ\tavgED\t*Indicates most favorable bp has more favorable partner or is "
+                  "more likely to be unpaired (competing coordinates are reported)\n")
+
+
+def fold(table, prefix, filt=-2, bp_path=None, write_log=True, engine=None, competition=1):
     """The whole stage for one scan table; files are named like the reference's (`prefix` = "<input>.ScanFold.").
-    engine: a scanfold_amd Engine -> the pair tabulation runs on the GPU (DeviceTabulation); None -> numpy."""
+    engine: a scanfold_amd Engine -> the pair tabulation runs on the GPU (DeviceTabulation); None -> numpy.
+    competition: 1 (default) = competing partners resolved, CT files + final_partners_test.bp (ScanFold-Fold.py:860-1074);
+    0 = competition allowed: DP files of every nucleotide's best partner + best_bps_test.bp (:1022-1038)."""
     tab = Tabulation(table) if engine is None else DeviceTabulation(table, engine)
     res = best_partners(tab, prefix + "log.txt" if write_log else None)
-    compete(tab, res, prefix + "final_partners.txt")
     z = tab.window_z
     meanz, stdz = float(np.mean(z)), float(np.std(z))
     one, two = float(meanz - stdz), float(meanz - 2 * stdz)
+    if competition == 0:
+        with open(prefix + "final_partners.txt", "w") as f:  # the reference opens the file and writes its header only
+            f.write(COMPETE_HEADER)
+        minz = min(z.tolist())
+        for name, f in ((str(filt), filt), ("no_filter", 10.0), ("-1", -1.0), ("-2", -2.0),
+                        ("mean_" + str(round(meanz, 2)), meanz), ("below_mean_" + str(round(one, 2)), one)):
+            write_dp(res, prefix + name + ".dp", float(f), minz)
+        write_bp(tab, res, bp_path or "best_bps_test.bp", tab.id, best=True)
+        return tab, res
+    bp_path = bp_path or "final_partners_test.bp"
+    compete(tab, res, prefix + "final_partners.txt")
     base = os.path.basename(prefix)
     for name, f in ((str(filt), filt), ("no_filter", 10.0), ("-1", -1.0), ("-2", -2.0),
                     ("below_mean_" + str(round(meanz, 2)), meanz), ("1sd_below_mean_" + str(round(one, 2)), one),
@@ -405,14 +435,14 @@ def main(argv=None):
     parser = argparse.ArgumentParser(description="ScanFold-Fold on vectorised tables")
     parser.add_argument('-i', '--input', type=str, required=True, help='input filename')
     parser.add_argument('-f', type=int, default=-2, help='filter value')
-    parser.add_argument('-c', type=int, default=1, help='Competition (1 for disallow competition; 0 is not implemented)')
+    parser.add_argument('-c', type=int, default=1, help='Competition (1 for disallow competition, 0 for allow; 1 by default)')
     parser.add_argument('-id', type=str, help='Accession number or ID of input sequence; creates properly named BP files.')
     args = parser.parse_args(argv)
-    if args.c != 1:
-        raise NotImplementedError("-c 0 (competition allowed, DP files) is not implemented")
+    if args.c not in (0, 1):  # upstream runs neither branch and writes the two logs only
+        raise ValueError("-c must be 1 (no competition allowed) or 0 (competition allowed)")
     table = ScanTable.from_file(args.input, args.id)
     print("Sequence length: " + str(len(set((table.starts[:, None] + np.arange(len(table.structs[0]))).ravel().tolist()))) + "nt")
-    fold(table, str(args.input) + ".ScanFold.", filt=int(args.f))
+    fold(table, str(args.input) + ".ScanFold.", filt=int(args.f), competition=int(args.c))
     print("ScanFold-Fold complete, find results in...")
     return 0
 

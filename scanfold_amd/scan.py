@@ -128,6 +128,8 @@ def rows_from_results(seq, starts, W, r, temperature, energies_dcal, structures,
 
 
 CHUNK_WINDOWS = 4096  # windows per engine call: the host formats chunk k while the GPU computes chunk k+1
+# what the last scan_record of this process spent where (seconds): `--timing` prints it per rank
+LAST_STATS = {}
 
 
 def _engine_chunks(work, lo, hi, chunk=None, threaded=True):
@@ -183,8 +185,8 @@ def _window_rows(text, W, step, w0, nw):
 
 
 def scan_record(seq, W, step, r, shuffle_type, temperature=37, engine=None, seed=0, shuffle_backend="device",
-                print_random=False, chunk=None, constraints=None, unbalanced="error"):
-    """All windows of one record -> list of TSV row strings.
+                print_random=False, chunk=None, constraints=None, unbalanced="error", windows=None):
+    """All windows of one record (or the range windows = (lo, hi) of them: a rank's shard) -> list of TSV row strings.
 
     temperature / constraints follow ScanFold-Scan.py: the native window's MFE, structure, centroid and
     ensemble diversity honour -t and -c (fc = RNA.fold_compound(frag, md); fc.hc_add_from_db(...), :382-418), while
@@ -200,10 +202,12 @@ def scan_record(seq, W, step, r, shuffle_type, temperature=37, engine=None, seed
         raise ValueError("shuffle_backend must be 'device' or 'python'")
     temperature = int(temperature)
     plain = constraints is None and temperature == 37
+    t_before = eng.params.temperature
     if not plain:
         eng.set_temperature(temperature)  # fails early for a parameter set without enthalpies
     starts = window_starts(len(seq), W, step)
     n_win = len(starts)
+    win_lo, win_hi = (0, n_win) if windows is None else (max(0, int(windows[0])), min(n_win, int(windows[1])))
     kind = _lib.SHUFFLE_DI if shuffle_type == "di" else _lib.SHUFFLE_MONO
     r_dev = r if shuffle_backend == "device" else 0
 
@@ -227,8 +231,29 @@ def scan_record(seq, W, step, r, shuffle_type, temperature=37, engine=None, seed
             out.update(native=fc["mfe"], structure=fc["structure"], centroid=fc["centroid"], ens_div=fc["mean_bp_dist"])
         return out
 
+    import time
     rows = []
-    for w0, res in _engine_chunks(work, 0, n_win, chunk=chunk, threaded=(shuffle_backend == "device")):
+    t_start = time.perf_counter()
+    LAST_STATS.clear()
+    LAST_STATS.update(windows=win_hi - win_lo, host_format_s=0.0, wait_engine_s=0.0)
+    try:
+        _scan_chunks(rows, work, win_lo, win_hi, chunk, shuffle_backend, starts, seq, W, r, shuffle_type, temperature,
+                     eng, print_random)
+    finally:
+        # the engine is shared (functions.energies, the RNA facade): leave it at the model it had (-t / -c switch
+        # between 37 C and T inside work())
+        eng.set_temperature(t_before)
+        LAST_STATS["total_s"] = time.perf_counter() - t_start
+    return rows
+
+
+def _scan_chunks(rows, work, win_lo, win_hi, chunk, shuffle_backend, starts, seq, W, r, shuffle_type, temperature, eng,
+                 print_random):
+    import time
+    t_mark = time.perf_counter()
+    for w0, res in _engine_chunks(work, win_lo, win_hi, chunk=chunk, threaded=(shuffle_backend == "device")):
+        LAST_STATS["wait_engine_s"] += time.perf_counter() - t_mark
+        t_mark = time.perf_counter()
         sub = starts[w0:w0 + len(res["ens_div"])]
         energies_dcal = res["energies"]
         if shuffle_backend == "python":
@@ -245,7 +270,8 @@ def scan_record(seq, W, step, r, shuffle_type, temperature=37, engine=None, seed
                 print([float(v) for v in dcal_to_float(energies_dcal[k])])
         rows.extend(rows_from_results(seq, sub, W, r, temperature, energies_dcal, res["structure"], res["centroid"],
                                       res["ens_div"], native_dcal=res.get("native")))
-    return rows
+        LAST_STATS["host_format_s"] += time.perf_counter() - t_mark
+        t_mark = time.perf_counter()
 
 
 def _drop_unmatched_brackets(cons):
@@ -267,22 +293,18 @@ def _drop_unmatched_brackets(cons):
     return cons
 
 
-def scan_record_sharded(seq, W, step, r, shuffle_type, temperature, eng, seed, rank, world):
-    """One record over `world` ranks (one process per GPU): contiguous window ranges, ONE all-gather of the
-    fixed-size records (scanfold_amd/dist.py), rows formatted on every rank (rank 0 writes them)."""
-    import torch
+def scan_record_sharded(seq, W, step, r, shuffle_type, temperature, eng, seed, rank, world, device=None, **kw):
+    """One record over `world` ranks (one process per GPU).  Every rank scans ITS contiguous window range exactly as a
+    single process would (scan_record: engine calls in chunks on a helper thread, z/p-scores and row formatting of
+    chunk k while the GPU works on chunk k+1) — so the host work shards with the folds — and ONE all-gather of
+    fixed-size row slots (scanfold_amd/dist.py: gather_rows) hands every rank all rows in window order; rank 0 writes
+    them.  A window's shuffles depend on (seed, absolute window index) only, so the rows do not depend on the sharding.
+    device: where the collective's tensors live (the rank's GPU for nccl = RCCL; None = host, gloo)."""
     from . import dist as sdist
-    starts = window_starts(len(seq), W, step)
-    n_win = len(starts)
-    kind = _lib.SHUFFLE_DI if shuffle_type == "di" else _lib.SHUFFLE_MONO
-    dev = torch.device("cuda", eng.device)
-
-    def produce(lo, hi):
-        res = eng.scan(seq, W, step, lo, hi - lo, r, kind, seed, raw=True)
-        return tuple(torch.from_numpy(res[k]).to(dev) for k in ("energies", "structure", "centroid", "ens_div", "ens_dG"))
-
-    m = sdist.scan_sharded(produce, n_win, W, r, rank, world, torch)
-    return rows_from_results(seq, starts, W, r, temperature, m["energies"], m["structure"], m["centroid"], m["ens_div"])
+    n_win = len(window_starts(len(seq), W, step))
+    lo, hi = sdist.shard_range(n_win, rank, world)
+    rows = scan_record(seq, W, step, r, shuffle_type, temperature, eng, seed=seed, windows=(lo, hi), **kw)
+    return sdist.gather_rows(rows, n_win, rank, world, W, device=device, want=(rank == 0))
 
 
 def build_parser():
@@ -309,6 +331,7 @@ def build_parser():
     parser.add_argument('--gpus', type=int, default=1, help='shard the windows of every record over this many GPUs '
                         '(one process per GPU, one RCCL all-gather per record)')
     parser.add_argument('-o', '--output', type=str, default=None, help='output path (default: upstream naming)')
+    parser.add_argument('--timing', action='store_true', help='print, per rank and record, where the time went')
     return parser
 
 
@@ -354,8 +377,16 @@ def main(argv=None):
         import torch.distributed as dist
         if args.shuffle_backend != "device":
             raise SystemExit("--gpus > 1 needs the device shuffle generator")
-        torch.cuda.set_device(eng.device)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", eng.device))
+        # SCANFOLD_DIST_BACKEND=gloo: the gather over host memory (several ranks on ONE GPU — RCCL refuses duplicate
+        # devices —, or the CPU build of the engine in the no-GPU test suite)
+        backend = os.environ.get("SCANFOLD_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            torch.cuda.set_device(eng.device)
+            dist_device = torch.device("cuda", eng.device)
+            dist.init_process_group("nccl", device_id=dist_device)
+        else:
+            dist_device = None
+            dist.init_process_group(backend)
     if args.shuffle_backend == "python":
         import random
         random.seed(args.seed)
@@ -368,18 +399,23 @@ def main(argv=None):
                 continue
             constraints = None
             if args.constraints is not None:
-                print("Considering constraint input")
+                if rank == 0:
+                    print("Considering constraint input")
                 constraints = read_constraints(args.constraints, len(seq))
             if world > 1:
-                if constraints is not None or temperature != 37:
-                    raise SystemExit("--gpus > 1 supports the plain scan only (no -c, -t 37)")
                 rows = scan_record_sharded(seq, window_size, step_size, randomizations, shuffle_type, temperature,
-                                           eng, args.seed, rank, world)
+                                           eng, args.seed, rank, world, device=dist_device,
+                                           print_random=(args.print_random == "on"), constraints=constraints,
+                                           unbalanced=args.constraint_unbalanced)
             else:
                 rows = scan_record(seq, window_size, step_size, randomizations, shuffle_type, temperature, eng,
                                    seed=args.seed, shuffle_backend=args.shuffle_backend,
                                    print_random=(args.print_random == "on"), constraints=constraints,
                                    unbalanced=args.constraint_unbalanced)
+            if args.timing:
+                print("scanfold_amd.scan timing rank %d/%d record %s: %s" % (rank, world, read_name, ", ".join(
+                    "%s=%s" % (k, ("%.4f" % v) if isinstance(v, float) else v) for k, v in sorted(LAST_STATS.items()))),
+                    file=sys.stderr, flush=True)
             if rank != 0:
                 continue
             w.write(header_line(read_name))

@@ -93,7 +93,7 @@ def scan_rows(seq, W, step, r, shuffle_type, temperature=37, engine=None, seed=0
         return dict(energies=en, native=fc["mfe"], structure=fc["structure"], centroid=pf["centroid"],
                     ens_div=pf["mean_bp_dist"])
 
-    rows, t_mfe, t_z, t_ed, t_struct = [], [], [], [], []
+    rows, t_mfe, t_z, t_p, t_ed, t_struct = [], [], [], [], [], []
     for w0, res in scanmod._engine_chunks(work, 0, n_win):
         sub = starts[w0:w0 + len(res["ens_div"])]
         E = scanmod.dcal_to_float(res["energies"])
@@ -111,12 +111,13 @@ def scan_rows(seq, W, step, r, shuffle_type, temperature=37, engine=None, seed=0
             if frag == scanmod.ALL_N_120:  # ScanFold.py:486-492
                 rows.append("%d\t%d\t%s\t0\t#DIV/0\t0\t0\t%s\t%s\t%s\t%s\n" % (i + 1, i + W, t, frag, scanmod.DOTS_120,
                                                                                scanmod.DOTS_120, str(gcs[k])))
-                mfe[k], zs[k], eds[k], structs[k] = 0.0, float("nan"), 0.0, scanmod.DOTS_120
+                mfe[k], zs[k], ps[k], eds[k], structs[k] = 0.0, float("nan"), 0.0, 0.0, scanmod.DOTS_120
                 continue
             rows.append("%d\t%d\t%s\t%s\t%s\t%s\t%s\t%s\t%s\t%s\t%s\n" % (i + 1, i + W, t, str(mfe[k]), str(zs[k]), str(ps[k]),
                                                                            str(eds[k]), frag, structs[k], cens[k], str(gcs[k])))
-        t_mfe += mfe; t_z += zs; t_ed += eds; t_struct += structs
+        t_mfe += mfe; t_z += zs; t_p += ps; t_ed += eds; t_struct += structs
     table = foldmod.ScanTable("", [i + 1 for i in starts], t_mfe, t_z, t_ed, [tseq[i:i + W] for i in starts], t_struct)
+    table.pvalues = t_p  # the fourth metric list of ScanFold.py (:691): only the scan-pvalue wig track reads it
     return rows, table
 
 
@@ -152,7 +153,9 @@ def build_parser():
     p.add_argument('--shapeD', action='store_true')
     p.add_argument('--shapeZ', action='store_true')
     p.add_argument('-f', type=int, default=-2, help='filter value')
-    p.add_argument('-c', type=int, default=1, help='Competition (1 for disallow competition)')
+    p.add_argument('-c', type=int, default=1, help='Competition (1 for disallow competition, 0 for allow; 1 by default)')
+    p.add_argument('--name', type=str, default="UserInput", help='name of data being analyzed (chrom= of the wig tracks)')
+    p.add_argument('--final_partners_wig', type=str, default="./IGV_BP_Zavg_metrics", help='final partners wig file path')
     p.add_argument('-s', type=int, default=1, help='step size')
     p.add_argument('-w', type=int, default=120, help='window size')
     p.add_argument('-r', type=int, default=100, help='randomizations')
@@ -174,8 +177,8 @@ def main(argv=None):
     args = build_parser().parse_args(argv)
     if args.algo != "rnafold":
         raise NameError("name 'RNAstructure' is not defined")  # upstream's rnastructure backend is never imported (ScanFold.py:40,439)
-    if args.c != 1:
-        raise NotImplementedError("-c 0 is not implemented")
+    if args.c not in (0, 1):
+        raise ValueError("-c must be 1 (no competition allowed) or 0 (competition allowed)")
     from . import params as _params
     eng = _lib.get_engine()
     eng.set_max_bp_span(args.span or 0)
@@ -208,10 +211,24 @@ def main(argv=None):
         if not args.dont_fold:
             table.id = read_name
             # ScanFold.py tabulates every window (its inline loop has no dropped first row, unlike ScanFold-Fold.py)
-            foldmod.fold(table, outname + ".ScanFold.", filt=int(args.f), bp_path=outname + ".bp", engine=eng)
-            for tag, label in (("no_filter", "NoFilter"), ("-1", "Zavg_-1"), ("-2", "Zavg_-2")):
-                writers.makedbn(outname + ".ScanFold." + tag, label)  # ScanFold.py:1487-1489
-            if not args.dont_extract:
+            if args.c == 0:  # competition allowed: DP files + the track of the best partners, no CT / dbn / motifs (ScanFold.py:1454-1465)
+                foldmod.fold(table, outname + ".ScanFold.", filt=int(args.f), bp_path=outname + ".ALL.bp", engine=eng,
+                             competition=0)
+            else:
+                tab, res = foldmod.fold(table, outname + ".ScanFold.", filt=int(args.f), bp_path=outname + ".bp", engine=eng)
+                for tag, label in (("no_filter", "NoFilter"), ("-1", "Zavg_-1"), ("-2", "Zavg_-2")):
+                    writers.makedbn(outname + ".ScanFold." + tag, label)  # ScanFold.py:1487-1489
+                # per-nucleotide mean z-score of the final partners, the track of the best partners (ScanFold.py:1491-1492)
+                writers.write_wig_dict(res.fin_z.tolist(), args.final_partners_wig + "." + outname + ".wig", args.name, step)
+                foldmod.write_bp(tab, res, outname + ".ALL.bp", tab.id, best=True)
+            # the scanned sequence and the four per-window metric tracks (ScanFold.py:1494-1500)
+            writers.write_fasta(seq, args.name + "." + outname + ".fa", args.name)
+            zlist = [("#DIV/0" if z != z else z) for z in table.z.tolist()]  # (all-N windows, ScanFold.py:486-492)
+            writers.write_wig(table.mfe.tolist(), step, args.name, outname + ".scan-MFE.wig")
+            writers.write_wig(zlist, step, args.name, outname + ".scan-zscores.wig")
+            writers.write_wig(table.pvalues, step, args.name, outname + ".scan-pvalue.wig")
+            writers.write_wig(table.ed.tolist(), step, args.name, outname + ".scan-ED.wig")
+            if args.c == 1 and not args.dont_extract:
                 with open(outname + ".ScanFold.-2.dbn") as f:
                     line = f.readlines()[2]
                 found = motifmod.extract_structures(line, seq)

@@ -3,6 +3,8 @@
 reference (ScanFoldFunctions.py)            here
 ------------------------------------------  ---------------------------------------------------------------
 write_wig(metric_list, step, name, path)    :626-642   same signature; IGV fixedStep track of a per-window metric
+write_wig_dict(nuc_dict, path, name, step)  :616-624   write_wig_dict(zscores, path, name, step): per-nucleotide mean z-score
+                                                       of the final partners
 write_fasta(nuc_dict, path, name)           :597-605   write_fasta(sequence, path, name)
 write_fai(nuc_dict, path, name)             :717-725   write_fai(sequence_length, path, name)
 makedbn(ctfile, name)                       :67-138    same signature: <ctfile>.ct -> <ctfile>.dbn; a pair that
@@ -11,7 +13,7 @@ The per-nucleotide dictionaries of NucZscore objects the reference passes around
 Outputs are pinned byte for byte by tests/golden/writers.json (the reference's functions run on the same inputs by
 tests/golden/make_golden_writers.py).  The CT / .bp / log writers of the Fold stage live in scanfold_amd/fold.py.
 Motif extraction, the motif refolds and their gff3 / dbn2ct files: scanfold_amd/motifs.py.
-Not reproduced: write_dp (competition-free mode) and the varna / PS plots of ScanFold.py:1484-1779.
+write_dp (competition-allowed mode) lives in scanfold_amd/fold.py.  Not reproduced: the varna / PS plots of ScanFold.py:1484-1779.
 """
 
 
@@ -22,6 +24,14 @@ def write_wig(metric_list, step, name, outputfilename):
             out.append("%s\n" % metric)
         else:
             out.append("%f\n" % metric)
+    with open(outputfilename, "w") as w:
+        w.write("".join(out))
+
+
+def write_wig_dict(zscores, outputfilename, name, step_size):
+    """One %f line per nucleotide (the reference walks its final-partner dictionary in coordinate order)."""
+    out = ["%s %s %s %s %s\n" % ("fixedStep", "chrom=" + name, "start=1", "step=" + str(step_size), "span=" + str(step_size))]
+    out += ["%f\n" % z for z in zscores]
     with open(outputfilename, "w") as w:
         w.write("".join(out))
 

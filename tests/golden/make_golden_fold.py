@@ -63,10 +63,21 @@ def main():
                                      "head": "".join(text.splitlines(True)[:60])}
                 else:
                     outputs[name] = text
-        cases.append({"L": L, "W": W, "step": step, "r": r, "seed": seed, "tsv": tsv, "outputs": outputs})
-        print("case", seed, "files:", len(outputs))
+        # the competition-allowed mode (ScanFold-Fold.py -c 0, :1022-1038): DP files of the best partners instead of CT files
+        with tempfile.TemporaryDirectory() as d:
+            with open(os.path.join(d, "scan.tsv"), "w") as f:
+                f.write(tsv)
+            subprocess.run([sys.executable, REF, "-i", "scan.tsv", "-c", "0"], cwd=d, check=True, capture_output=True)
+            outputs_c0 = {}
+            for name in sorted(os.listdir(d)):
+                if name == "scan.tsv" or name.endswith(".log.txt"):  # (the log is the same file as with -c 1)
+                    continue
+                outputs_c0[name] = open(os.path.join(d, name)).read()
+        cases.append({"L": L, "W": W, "step": step, "r": r, "seed": seed, "tsv": tsv, "outputs": outputs,
+                      "outputs_c0": outputs_c0})
+        print("case", seed, "files:", len(outputs), "+", len(outputs_c0), "with -c 0")
     with open(OUT, "w") as f:
-        json.dump({"generated_by": "tests/golden/make_golden_fold.py", "reference_cmd": "python ScanFold-Fold.py -i scan.tsv",
+        json.dump({"generated_by": "tests/golden/make_golden_fold.py", "reference_cmd": "python ScanFold-Fold.py -i scan.tsv  (outputs_c0: ... -c 0)",
                    "cases": cases}, f, indent=0)
     print("wrote", OUT, os.path.getsize(OUT), "bytes")
 

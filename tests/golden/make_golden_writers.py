@@ -18,18 +18,28 @@ class Nuc:
         self.nucleotide = n
 
 
+class Pair:
+    def __init__(self, z):
+        self.zscore = z
+
+
 def main():
     sys.dont_write_bytecode = True
     sys.modules.setdefault("RNA", types.ModuleType("RNA"))
     sys.path.insert(0, "/root/reference")
     import ScanFoldFunctions as sff
     cases = json.load(open(os.path.join(HERE, "fold_cases.json")))["cases"]
-    G = {"generated_by": "tests/golden/make_golden_writers.py", "wig": [], "fasta": [], "dbn": []}
+    G = {"generated_by": "tests/golden/make_golden_writers.py", "wig": [], "fasta": [], "dbn": [], "wig_dict": [], "dp": []}
     with tempfile.TemporaryDirectory() as d:
         for k, (metrics, step) in enumerate([([-1.25, 0.5, "#DIV/0!", 3, -0.0049999, 12.3456789], 1), ([0.1] * 3, 10)]):
             p = os.path.join(d, "w%d.wig" % k)
             sff.write_wig(metrics, step, "chr%d" % k, p)
             G["wig"].append({"metrics": metrics, "step": step, "name": "chr%d" % k, "out": open(p).read()})
+        # write_wig_dict (ScanFoldFunctions.py:616-624): one mean z-score per nucleotide of the final partners
+        for k, (zs, step) in enumerate([([-2.5, -0.333333333, 0.0, 1.0, -1e-7, 12.3456789], 1), ([0.25, -3.0], 5)]):
+            p = os.path.join(d, "wd%d.wig" % k)
+            sff.write_wig_dict({i + 1: Pair(z) for i, z in enumerate(zs)}, p, "rec%d" % k, step)
+            G["wig_dict"].append({"zscores": zs, "step": step, "name": "rec%d" % k, "out": open(p).read()})
         for seq, name in (("ACGUACGGGAUC", "rec1"), ("G" * 70, "a longer name|with|bars")):
             nd = {i + 1: Nuc(ch) for i, ch in enumerate(seq)}
             pf, pi = os.path.join(d, "x.fa"), os.path.join(d, "x.fai")

@@ -117,3 +117,37 @@ def test_engine_scan_sharded_over_two_gloo_ranks_equals_single_process(tmp_path)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "RANK0_ROWS_EQUAL=True n=12" in out.stdout and "RANK1_ROWS_EQUAL=True n=12" in out.stdout, \
         out.stdout + out.stderr[-1500:]
+
+
+def _write_fasta(path, seq, name="rec1"):
+    with open(path, "w") as f:
+        f.write(">%s test record\n" % name)
+        for k in range(0, len(seq), 60):
+            f.write(seq[k:k + 60] + "\n")
+
+
+def _run_cli(args, env, timeout=900):
+    return subprocess.run([sys.executable, "-m", "scanfold_amd.scan"] + args, cwd=ROOT, capture_output=True, text=True,
+                          timeout=timeout, env=dict(os.environ, OMP_NUM_THREADS="1", **env))
+
+
+def test_cli_gpus_2_over_gloo_writes_the_single_process_tsv(tmp_path):
+    """`python -m scanfold_amd.scan --gpus 2` end to end on the CPU build of the engine (tests/emul), gloo gather: every
+    rank scans and FORMATS its own window range, one gather of row slots, rank 0 writes — the file equals the one-process
+    file byte for byte, also with a constraint line (-c) and an odd number of windows (ragged last shard)."""
+    from emul_engine import build, EMUL_LIB
+    build()
+    seq = "".join("ACGT"[k] for k in np.random.default_rng(8).integers(0, 4, 83))
+    fa = tmp_path / "in.fa"
+    _write_fasta(fa, seq)
+    cons = tmp_path / "cons.txt"
+    cons.write_text(">rec1\n" + seq + "\n" + "".join("x" if k % 11 == 0 else "." for k in range(len(seq))) + "\n")
+    env = {"SCANFOLD_LIB_PATH": EMUL_LIB, "SCANFOLD_DEVICE": "0", "SCANFOLD_DIST_BACKEND": "gloo"}
+    for extra in ([], ["-c", str(cons)]):
+        base = ["-i", str(fa), "-w", "30", "-s", "6", "-r", "3", "-type", "di", "--seed", "4"] + extra
+        one, two = tmp_path / "one.tsv", tmp_path / "two.tsv"
+        a = _run_cli(base + ["-o", str(one)], env)
+        assert a.returncode == 0, a.stderr[-2000:]
+        b = _run_cli(base + ["--gpus", "2", "-o", str(two)], env)
+        assert b.returncode == 0, b.stderr[-2000:]
+        assert one.read_bytes() == two.read_bytes() and one.read_text().count("\n") == 1 + 9, extra

@@ -38,6 +38,22 @@ def test_fold_outputs_are_byte_identical_to_the_reference(cases, tmp_path, monke
                 assert text == exp, (c["seed"], name)
 
 
+def test_competition_allowed_mode_writes_the_reference_dp_files(cases, tmp_path, monkeypatch):
+    """`-c 0` (ScanFold-Fold.py:1022-1038; write_dp :380-394): DP files of the best partners for the five filters,
+    best_bps_test.bp, a final-partners log with its header only — byte for byte what the reference wrote."""
+    for c in cases:
+        d = tmp_path / ("c0_%d" % c["seed"])
+        d.mkdir()
+        (d / "scan.tsv").write_text(c["tsv"])
+        monkeypatch.chdir(d)
+        assert fold.main(["-i", "scan.tsv", "-c", "0"]) == 0
+        got = sorted(n for n in os.listdir(d) if n != "scan.tsv" and not n.endswith(".log.txt"))
+        assert got == sorted(c["outputs_c0"]), (c["seed"], got)
+        for name, exp in c["outputs_c0"].items():
+            assert (d / name).read_text() == exp, (c["seed"], name)
+        assert len([n for n in got if n.endswith(".dp")]) == 5
+
+
 def test_group_sums_are_numpy_sums_bit_for_bit():
     rng = np.random.default_rng(1)
     vals = np.round(rng.normal(0, 2, 120000), 2)
@@ -174,6 +190,11 @@ def test_device_tabulation_rejects_bad_tables(emul):
         emul.tabulate_pairs(["((..", "...."], [1, 2], z, z, z)
     with pytest.raises(ScanFoldHipError, match="scan table"):
         emul.tabulate_pairs(["(..)", "...."], [2, 2], z, z, z)
+    # rows of nothing but '(' are deeper than the bracket stack (W/2 + 1 entries per window): rejected, nothing
+    # written out of bounds (the emulation build aborts on heap corruption; the sanitizer build sees the store itself)
+    for W in (30, 400):
+        with pytest.raises(ScanFoldHipError, match="scan table"):
+            emul.tabulate_pairs(["(" * W, "(" * (W // 2 + 2) + "." * (W - W // 2 - 2)], [1, 2], z, z, z)
     g = emul.tabulate_pairs(["(..)", "(..)"], [1, 2], np.array([-1.0, -2.0]), np.array([-3.0, -4.0]), np.array([1.0, 2.0]))
     assert g["k"].tolist() == [1, 2, 2, 3, 4, 4, 5] and g["j"].tolist() == [4, 2, 5, 3, 1, 4, 2]
     assert g["windows"].tolist() == [1, 1, 1, 2, 1, 1, 1] and g["first_window"].tolist() == [0, 0, 1, 0, 0, 1, 1]

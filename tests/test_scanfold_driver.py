@@ -78,6 +78,17 @@ def test_scan_then_fold_pipeline(emul, oracle, tmp_path, monkeypatch):
     paired = sum(1 for ln in ct[1:-1] if int(ln.split()[4]) != 0)
     assert paired == 2 * fold.structure_string(tab, res, -1.0).count("(")
     assert os.path.exists(tmp_path / (base + ".ScanFold.final_partners.txt")) and os.path.exists(tmp_path / (base + ".bp"))
+    # exports of the combined driver (ScanFold.py:1491-1500): per-nucleotide z track of the final partners, the track of
+    # the best partners, the scanned sequence, one wig track per scan metric — values are the table's own columns
+    zw = (tmp_path / ("IGV_BP_Zavg_metrics." + base + ".wig")).read_text().split("\n")
+    assert zw[0] == "fixedStep chrom=UserInput start=1 step=2 span=2" and len(zw) == len(seq) + 2
+    assert zw[1:-1] == ["%f" % v for v in res.fin_z.tolist()]
+    assert (tmp_path / (base + ".ALL.bp")).read_text().count("\n") == 7 + len(seq)
+    assert (tmp_path / ("UserInput." + base + ".fa")).read_text() == ">UserInput\n" + tseq + "\n"
+    for tag, col in (("MFE", 3), ("zscores", 4), ("pvalue", 5), ("ED", 6)):
+        wl = (tmp_path / (base + ".scan-%s.wig" % tag)).read_text().split("\n")
+        assert wl[0] == "fixedStep chrom=UserInput start=1 step=2 span=2"
+        assert wl[1:-1] == ["%f" % float(r[col]) for r in rows], tag
     # dot-bracket files + motif extraction / refolds (ScanFold.py:1487-1489, 1582-1776): every gff3 line is the
     # constrained refold of a top-level helix of the -2 line, checked against the oracle
     dbn = (tmp_path / (base + ".ScanFold.-2.dbn")).read_text().split("\n")
@@ -99,6 +110,28 @@ def test_scan_then_fold_pipeline(emul, oracle, tmp_path, monkeypatch):
             assert os.path.exists(tmp_path / (base + "_motif_%d.ct" % num))
     finally:
         oracle.set_constraint(None, None)
+
+
+def test_competition_allowed_mode_of_the_combined_driver(emul, tmp_path, monkeypatch):
+    """-c 0 (ScanFold.py:1454-1465): DP files of the best partners and their .ALL.bp track, no CT / dbn / motif files."""
+    monkeypatch.setattr(_lib, "_engine", emul)
+    monkeypatch.chdir(tmp_path)
+    seq = "".join("ACGU"[k] for k in np.random.default_rng(12).integers(0, 4, 64))
+    (tmp_path / "in.fa").write_text(">r0\n" + seq + "\n")
+    assert sfd.main(["in.fa", "-w", "30", "-s", "3", "-r", "4", "--type", "mono", "--seed", "1", "-c", "0"]) == 0
+    names = sorted(os.listdir(tmp_path))
+    base = "r0.win_30.stp_3.rnd_4.shfl_mono"
+    assert len([n for n in names if n.endswith(".dp")]) == 5 and base + ".ALL.bp" in names
+    assert not [n for n in names if n.endswith((".ct", ".dbn", ".gff3"))]
+    rows = (tmp_path / (base + ".out")).read_text().split("\n")[1:-1]
+    table = fold.ScanTable("r0", [int(r.split("\t")[0]) for r in rows], [float(r.split("\t")[3]) for r in rows],
+                           [float(r.split("\t")[4]) for r in rows], [float(r.split("\t")[6]) for r in rows],
+                           [r.split("\t")[7] for r in rows], [r.split("\t")[8] for r in rows])
+    res = fold.best_partners(fold.Tabulation(table))
+    minz = min(table.z.tolist())
+    exp = "".join("%d\t%d\t%f\n" % (k, j, float((-1 / minz) * z) / minz)
+                  for k, j, z in zip(res.coords.tolist(), res.best_j.tolist(), res.best_mean_z.tolist()) if z < 10.0)
+    assert (tmp_path / (base + ".ScanFold.no_filter.dp")).read_text() == exp
 
 
 def test_shape_and_constraint_paths_of_the_combined_driver(emul, oracle, tmp_path, monkeypatch):

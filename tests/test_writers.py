@@ -15,6 +15,13 @@ def test_wig(tmp_path):
         assert p.read_text() == it["out"]
 
 
+def test_wig_dict(tmp_path):
+    for it in G["wig_dict"]:
+        p = tmp_path / "wd.wig"
+        writers.write_wig_dict(it["zscores"], str(p), it["name"], it["step"])
+        assert p.read_text() == it["out"]
+
+
 def test_fasta_and_fai(tmp_path):
     for it in G["fasta"]:
         pf, pi = tmp_path / "x.fa", tmp_path / "x.fai"

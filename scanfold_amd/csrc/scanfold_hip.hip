@@ -54,8 +54,6 @@ struct Ctx {
   int max_bp_span = 0;  // RNA.md().max_bp_span; <= 0: no limit
   int pf_kernel = 0;  // 0: LDS-resident kernel where it fits; 1: device-memory tables (SCANFOLD_PF_KERNEL=global)
   int pf_blocks_per_cu = 4;  // 256 VGPRs per thread: 2 waves per SIMD
-  int pf_run_len = 0;        // > 0: forced run length of the shared-inside mode
-  int mfe_static = 0;        // SCANFOLD_MFE_STATIC=1: folds dealt to the workgroups in advance (measurement switch)
   int pf_share_inside = 1;   // sf_scan, step 1: consecutive native windows share their inside tables (SCANFOLD_PF_SHARE=0: off)
 } g;
 
@@ -225,7 +223,6 @@ int launch_pf(const uint8_t *d_seqs, int n, int row_stride, int W, double *d_dG,
         const double cost = per * (1.0 + resumed * (t - 1));
         if (cost < best) { best = cost; run_len = t; }
       }
-      if (g.pf_run_len > 0) run_len = g.pf_run_len < n ? g.pf_run_len : n;  // SCANFOLD_PF_RUN_LEN (tests)
       if (run_len > 1) {
         grid = (n + run_len - 1) / run_len < g.n_cu ? (n + run_len - 1) / run_len : g.n_cu;
         int rc = ensure(g.pf_share, (size_t)grid * SF_PFL_SHARE_DOUBLES(W) * sizeof(double));
@@ -330,7 +327,7 @@ int launch_mfe(const uint8_t *d_seqs, int n, int W, int32_t *d_out, hipStream_t 
     if ((rc = prof.begin(st))) return rc;
     sf_fast_launch(grid, threads, lds, st, d_seqs, n, W, (const SfDevParams *)g.dP, (const SfFastParams *)g.dF,
                      (int16_t *)g.fast_scratch.p, d_out, d_cnt, d_list, trace_stride, d_db, (int *)g.status.p,
-                     g.mfe_static ? (int *)nullptr : d_work);
+                     d_work);
     HIPCHK(hipGetLastError());
     if ((rc = prof.end(st))) return rc;
     // folds that left the int16 range are redone exactly
@@ -407,11 +404,7 @@ int sf_init(int device_ordinal) {
   HIPCHK(sf_pfl_configure());
   if (const char *pk = getenv("SCANFOLD_PF_KERNEL")) g.pf_kernel = (strcmp(pk, "global") == 0);
   if (const char *ps = getenv("SCANFOLD_PF_SHARE")) g.pf_share_inside = atoi(ps) != 0;
-  if (const char *pr = getenv("SCANFOLD_PF_RUN_LEN")) g.pf_run_len = atoi(pr);
-  if (const char *pb = getenv("SCANFOLD_PF_BLOCKS_PER_CU")) g.pf_blocks_per_cu = atoi(pb) > 0 ? atoi(pb) : 4;
-  if (const char *ms = getenv("SCANFOLD_MFE_STATIC")) g.mfe_static = atoi(ms) != 0;
-  const char *ff = getenv("SCANFOLD_FORCE_FULL");
-  g.force_full = (ff && ff[0] == '1');
+  g.force_full = 0;  // (sf_set_kernel_mode(1) selects the general kernels)
   g.init = true;
   g.have_params = false;
   return SF_OK;

@@ -11,17 +11,9 @@
 // scheduling hint: the next `n` instructions of class `mask` (0x100 = LDS read, 0x2 = VALU) form one group
 #define SF_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier((mask), (n), 0)
 // nothing is scheduled across this point (bounds how many loads the compiler keeps in flight = live registers)
-#ifdef SF_NO_FENCE
-#define SF_SCHED_FENCE() ((void)0)
-#else
 #define SF_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-#endif
 // the value must be computed by this point (keeps the arithmetic next to the loads that feed it)
-#ifdef SF_NO_PIN
-#define SF_PIN(x) ((void)0)
-#else
 #define SF_PIN(x) asm volatile("" : "+v"(x))
-#endif
 // v of lane l (l wave-uniform, known only at run time)
 #define SF_LANE_READ(v, l) __builtin_amdgcn_readlane((v), (l))
 // a value that is the same in every lane of the wave: tell the compiler (keeps derived index math scalar)

@@ -45,62 +45,37 @@
 #include "sf_pk16.h"
 
 #define SF_FAST_NR 34
-// sf_mfe_pk.hip.h only — 1: the workgroup first builds c + ExtLoop for all cells in LDS (sf_fast_ext_table) and the
-// exterior sweep reads that; 0: the sweep reads the c scratch from device memory (L2) and looks the terms up
-// itself.  (This file's kernel publishes c + ExtLoop into the scratch in the first place.)
-#ifndef SF_EXT_TABLE
-#define SF_EXT_TABLE 0
-#endif
 // even diagonals below this one run the size-tested cell code (some special loops do not exist yet: d <= 11)
 #define SF_FAST_TINY_D0 12
 // even diagonals below this one skip whole batches of loop sizes above the limit (CH); from here to 36 the skipped
 // work is small and the unbroken straight-line code is faster (measured: 20 / 24 / 28 / 36 -> 87.5 / 87.1 / 87.0 / 87.9 ms)
 #define SF_FAST_CHUNK_D0 28
-#ifndef SF_FAST_SPLIT
 #define SF_FAST_SPLIT 1  // long diagonals: the idle second wave of a group takes part of the cell's work
-#endif
 // split steps at W <= 128: 1 = ONE helper wave serves both diagonals of a step, on a compacted list of the cells that
 // can pair (3 of 8): the special / bulge / 1xn block runs once per step instead of twice
 // (W < SF_HELP_MERGE_MAXW only.  With folds handed out dynamically the merge measures +3.6 % at W=80, +2.3 % at W=100,
 // +1.1 % at W=110, +1.5 % at W=116 and -2.9 % at W=120, -1.4 % at W=128: the compacted lanes read scattered words, three or four deep
 // in the LDS banks, and at the widths where LDS cycles are tightest that costs more than the saved pass.)
-#ifndef SF_HELP_MERGE_MAXW
 #define SF_HELP_MERGE_MAXW 118
-#endif
-#ifndef SF_HELP_MERGE
 #define SF_HELP_MERGE 1
-#endif
 // split steps at W > 128 (four waves per diagonal): 1 = the group's outer waves help the two middle ones
-#ifndef SF_FAST_SPLIT_256
 #define SF_FAST_SPLIT_256 1
-#endif
-// split steps: the helper wave takes (terms / 2 - bias) terms of the multiloop split, the ones with the largest m.
-// NG = 128: none (the helper's special-loop work already balances the first wave; measured: any share, same time);
-// NG = 256: the split is most of a cell there
-#ifndef SF_DML_HELPER_BIAS_128
-#define SF_DML_HELPER_BIAS_128 100000
-#endif
-#ifndef SF_DML_HELPER_BIAS_256
+// split steps of the wide kernel (NG = 256, where the split is most of a cell): the helper waves take (terms / 2 - bias)
+// terms of the multiloop split, the ones with the largest m.  The narrow kernel's helpers take none: their special-loop
+// work already balances the main wave (any share measured the same or worse in rounds 2 and 3).
 #define SF_DML_HELPER_BIAS_256 26
-#endif
-#define SF_DML_HELPER_BIAS(ng) ((ng) == 256 ? SF_DML_HELPER_BIAS_256 : SF_DML_HELPER_BIAS_128)
+#define SF_DML_HELPER_BIAS(ng) ((ng) == 256 ? SF_DML_HELPER_BIAS_256 : 100000)
 // loop sizes per batch of reads in the bulge / 1xn minima (narrow / wide kernel; measured 2, 3, 4, 6: W=120 best at
 // 3 by 0.6 %, W=200 at 6 by 3.5 %)
-#ifndef SF_HELP_NB_128
 #define SF_HELP_NB_128 3
-#endif
-#ifndef SF_HELP_NB_256
 #define SF_HELP_NB_256 6
-#endif
 #define SF_INF16 30000
 #define SF_FAST_THRESH 10000
 #define SF_FAST_OVF (-12000)
 #define SF_FAST_MAXPARAM 2500
 #define SF_FAST_MAXW 256
 #define SF_FAST_BIG 60000
-#ifndef SF_FAST_WAVES_PER_SIMD
 #define SF_FAST_WAVES_PER_SIMD 4  // 4 workgroups of 4 waves per CU (W <= 128): at most 128 VGPRs
-#endif
 
 struct SfFastParams {
   int32_t NIN[32];   // [a]  min(max_ninio, a * ninio)
@@ -287,9 +262,7 @@ struct SfFastCtx {
 // constant; the final batch is placed to end exactly at the stretch's last term (it may overlap the one before: a
 // minimum does not mind seeing a term twice).  A stretch shorter than eight terms is ONE batch whose surplus
 // terms repeat the last one, so that all of its reads are in flight together.  len is wave-uniform.
-#ifndef SF_SPLIT_NB
 #define SF_SPLIT_NB 8  // terms per batch = LDS read pairs in flight
-#endif
 template <bool AP, bool BP>
 __device__ __forceinline__ void sf_fast_split_stretch(const int16_t *pa, const int16_t *pb, const int len, const int S,
                                                       int &dec, int &dec2) {
@@ -866,53 +839,6 @@ __device__ inline int sf_fast_traceback(const SfFastCtx &X, const int32_t *f5s, 
 // the odd ones.  c[.,.] of diagonal d+1 does not depend on diagonal d (an enclosed pair spans at most d-1, the
 // multiloop split of d+1 reads fML spans <= d-3), only fML[d+1] needs its two neighbours on d — so the pair
 // (d, d+1) is computed concurrently by the two groups, then group 1 adds the neighbour term after one barrier.
-// c[i,j] + ExtLoop(i,j) for every cell, from the c scratch in device memory into LDS (same triangular layout),
-// by ALL threads of the workgroup: wave w takes the rows i = w+1, w+1+nw, ...; the lanes run along a row.
-// Leaves only one add and one min per cell to the single-wave exterior sweep.
-__device__ __forceinline__ void sf_fast_ext_table(const SfFastCtx &X, const int W, const int tid, const int nthreads,
-                                                  const int16_t *tExt, int16_t *etab) {
-  const uint8_t *S = X.S;
-  const int lane = tid & 63, nw = nthreads >> 6, w = tid >> 6;
-  constexpr int RB = 8;  // rows per batch: 2*RB device-memory reads in flight per lane before anything waits
-  for (int i0 = w + 1; i0 <= W - SFD_TURN - 1; i0 += nw * RB) {
-    int cv[RB][2];
-#pragma unroll
-    for (int r = 0; r < RB; r++) {
-      const int i = i0 + r * nw;
-#pragma unroll
-      for (int h = 0; h < 2; h++) {
-        const int j = i + SFD_TURN + 1 + lane + 64 * h;
-        cv[r][h] = (i <= W - SFD_TURN - 1 && j <= W) ? (int)X.cg[SF_CGIDX(i, j)] : SF_INF16;
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < RB; r++) {
-      const int i = i0 + r * nw;
-      if (i <= W - SFD_TURN - 1) {
-        const int si = S[i], sim1 = S[i - 1];
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-          const int j = i + SFD_TURN + 1 + lane + 64 * h;
-          if (j <= W) {
-            const int type = j - i <= X.maxd ? X.tPair[si * 8 + S[j]] : 0;
-            int e = SF_INF16;
-            if (type) {
-              const int sj1 = S[j + 1];
-              int ext;
-              if (i > 1 && j < W) ext = tExt[SF_TIDX(type, sim1, sj1)];
-              else if (i > 1) ext = X.tD5[type * 5 + sim1];
-              else if (j < W) ext = X.tD3[type * 5 + sj1];
-              else ext = 0;
-              e = sfd_min(cv[r][h] + ext + (type > 2 ? X.TAU : 0), SF_INF16);
-            }
-            etab[SF_CGIDX(i, j)] = (int16_t)e;
-          }
-        }
-      }
-    }
-  }
-}
-
 // Exterior loop f5[j] = min(f5[j-1], min_i f5[i-1] + c[i,j] + ExtLoop(i,j)), the energy / overflow record and
 // (for native windows) the traceback: ONE wave, after the fill.  No workgroup barrier inside.
 // NQ = columns per lane (ceil(W/64)).  etab: c[i,j] + ExtLoop(i,j), laid out like the c scratch, prepared in LDS
@@ -1035,18 +961,10 @@ __device__ __forceinline__ void sf_fast_exterior(const SfFastCtx &X, const int W
 // every step of the long-diagonal phase, in the slack it has there (loads issued before its own work, consumed after
 // it), and only the rows the last step completes are left for the end of the fold.  One scratch per workgroup.
 // State: lane l holds f3[j+1] of its columns j = l+1, l+65, ...; f3 of the row above the next one.
-#ifndef SF_DEFER
 #define SF_DEFER 1
-#endif
-#ifndef SF_DEFER_256
 #define SF_DEFER_256 1  // the wide kernel trails too (four columns per lane)
-#endif
-#ifndef SF_DEFER_W200
 #define SF_DEFER_W200 1
-#endif
-#ifndef SF_DEFER_ROWS_256
 #define SF_DEFER_ROWS_256 2
-#endif
 template <int NQ>
 struct SfTrail {
   int F[NQ];   // lane l: f3[j+1] for the columns j = l+1+64q (0 until row j+1 has been swept)
@@ -1225,8 +1143,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
     int fetched = 0;
     if (tid == 0) {
       S[0] = 0; S[W + 1] = 0; flag[0] = 0;
-      // (work_ctr == nullptr: the static deal of rounds 1-2, kept as a measurement switch: SCANFOLD_MFE_STATIC=1)
-      fetched = work_ctr ? (int)gridDim.x + atomicAdd(work_ctr, 1) : seq + (int)gridDim.x;
+      fetched = (int)gridDim.x + atomicAdd(work_ctr, 1);
     }
     __syncthreads();
     int next_seq = n;  // (set in the third step; W >= 16 has at least five)
@@ -1452,10 +1369,6 @@ static inline void sf_fast_geometry(int W, int n_cu, int n, int *grid, int *thre
   // surplus workgroups as a second round (measured at W=100: 5 per CU 3.31 M folds/s, 4 per CU 4.12 M).
   const int by_waves = (4 * SF_FAST_WAVES_PER_SIMD) / (nt / 64);
   if (per_cu > by_waves) per_cu = by_waves;
-  if (const char *e = getenv("SCANFOLD_MFE_BLOCKS_PER_CU")) {  // experiments: fewer resident workgroups per CU
-    const int v = atoi(e);
-    if (v >= 1 && v < per_cu) per_cu = v;
-  }
   if (per_cu < 1) per_cu = 1;
   long long gsz = (long long)n_cu * per_cu;
   if (gsz > n) gsz = n;

@@ -79,13 +79,11 @@ __global__ __launch_bounds__(NT) void sf_pf_fast_kernel(const uint8_t *__restric
         const int type = j - i <= D->max_pair_dist ? D->pair[S[i]][S[j]] : 0;
         const int si1 = S[i + 1], sj1 = S[j - 1];
         // generic interior sums of this cell from those of the enclosed cell
-#ifndef SF_PFABL_UIN
 #pragma unroll
         for (int u = 30; u >= 6; --u)
           if (!G || u <= umax) H[u - 4] = H[u - 6] + (PT(T.QBI, d - 2 - u, i + 3) + PT(T.QBI, d - 2 - u, i + u - 1)) * X->ninio[u - 4];
         if (!G || umax >= 5) H[1] = (PT(T.QBI, d - 7, i + 3) + PT(T.QBI, d - 7, i + 4)) * X->ninio[1];
         if (!G || umax >= 4) H[0] = PT(T.QBI, d - 6, i + 3) * X->ninio[0];
-#endif
         double qbij = 0.0;
         if (type) {
           double z = sfx_hairpin(D, X, S, i, j, type);
@@ -127,10 +125,8 @@ __global__ __launch_bounds__(NT) void sf_pf_fast_kernel(const uint8_t *__restric
             z += gb * tau_out + g1 * X->mismatch1nI[type][si1][sj1] + gg * X->mismatchI[type][si1][sj1];
           }
           double ml = 0.0;
-#ifndef SF_PFABL_ML
 #pragma unroll 4
           for (int a = SFD_TURN + 2; a <= d - SFD_TURN - 2; a++) ml += PT(T.QM, a - 2, i + 1) * PT(T.QM1, d - 1 - a, i + a);
-#endif
           z += ml * X->MLclosing * sfx_mlstem(X, sfd_rtype(type), sj1, si1);
           qbij = z;
         }
@@ -145,10 +141,8 @@ __global__ __launch_bounds__(NT) void sf_pf_fast_kernel(const uint8_t *__restric
           if (type) m1 += qbij * sfx_mlstem(X, type, i > 1 ? sp1 : -1, j < W ? sq1 : -1);
           PT(T.QM1, d, i) = m1;
           double m = m1;
-#ifndef SF_PFABL_QM
 #pragma unroll 4
           for (int a = 1; a <= d - SFD_TURN - 1; a++) m += (mlb[a] + PT(T.QM, a - 1, i)) * PT(T.QM1, d - a, i + a);
-#endif
           PT(T.QM, d, i) = m;
         }
       }
@@ -228,7 +222,6 @@ __global__ __launch_bounds__(NT) void sf_pf_fast_kernel(const uint8_t *__restric
         double a0 = 0.0, a1 = 0.0;
         if (i > 1) {
           a0 = PT(T.A0, d + 1, i - 1) * X->MLbase + PT(T.OBW, d + 1, i - 1);
-#ifndef SF_PFABL_A1
           {
             // closers (kk, j) with kk = j - dd >= 1: a per-thread bound, no test inside the loop
             const int ddmax = sfd_min(W - 1, j - 1);
@@ -242,7 +235,6 @@ __global__ __launch_bounds__(NT) void sf_pf_fast_kernel(const uint8_t *__restric
             if (dd <= ddmax) a1 += PT(T.OBW, dd, j - dd) * PT(T.QM, dd - d - 2, j - dd + 1);
             a1 += a1b;
           }
-#endif
         }
         PT(T.A0, d, i) = a0;
         PT(T.A1, d, i) = a1;
@@ -307,7 +299,6 @@ __global__ __launch_bounds__(NT) void sf_pf_fast_kernel(const uint8_t *__restric
             o += gb * (rt > 2 ? xTAU : 1.0) + g1 * X->mismatch1nI[rt][sq1][sp1] + gg * X->mismatchI[rt][sq1][sp1];
             // (i,j) as a stem of a multiloop closed by (k,l): indexed by the span dd = l - i
             double mlsum = 0.0;
-#ifndef SF_PFABL_MLSUM
             {
               // closers (k, l) with l = i + dd <= W: per-thread bound; dd = d+1 has an empty right part
               const int ddmax = sfd_min(W - 1, W - i);
@@ -326,7 +317,6 @@ __global__ __launch_bounds__(NT) void sf_pf_fast_kernel(const uint8_t *__restric
               }
               mlsum += ms2;
             }
-#endif
             o += mlsum * sfx_mlstem(X, type, sp1, sq1);
           }
         }

@@ -115,22 +115,25 @@ def randomizer(frag):
 
 
 def simple_transcribe(seq):
-    for _ch in seq:
-        return seq.replace("T", "U")
+    """T -> U.  (Upstream returns from inside a loop over the characters, so an empty string gives None.)"""
+    return seq.replace("T", "U") if seq else None
+
+
+_SHUFFLE_MESSAGE = "Shuffle type not properly designated; please input \"di\" or \"mono\""
 
 
 def scramble(text, randomizations, type):
-    frag = str(text)
-    frag_seqs = []
+    """`randomizations` shuffled copies (ScanFoldFunctions.py:834-851): "di" transcribes first and keeps the dinucleotide
+    counts, "mono" permutes; anything else prints upstream's message and yields no shuffles.  One generator draw
+    sequence per copy, in order — the strings under random.seed() are upstream's (tests/test_golden_host.py)."""
+    window = str(text)
     if type == "di":
-        frag = simple_transcribe(frag)
-        for _ in range(randomizations):
-            frag_seqs.append(dinuclShuffle(frag))
-    elif type == "mono":
-        frag_seqs = [randomizer(frag) for _ in range(randomizations)]
-    else:
-        print("Shuffle type not properly designated; please input \"di\" or \"mono\"")
-    return frag_seqs
+        window = simple_transcribe(window)
+        return [dinuclShuffle(window) for _ in range(randomizations)]
+    if type == "mono":
+        return [randomizer(window) for _ in range(randomizations)]
+    print(_SHUFFLE_MESSAGE)
+    return []
 
 
 # ----------------------------------------------------------------------------- folds
@@ -171,43 +174,49 @@ def rna_folder(arg):
 
 
 # ----------------------------------------------------------------------------- statistics
+def count_below_native(energy_list):
+    """How many entries of the list are strictly below its first one (the native fold is never below itself)."""
+    values = [float(e) for e in energy_list]
+    return sum(1 for e in values if e < values[0]), len(values)
+
+
 def pvalue_function(energy_list, randomizations):
-    below_native = 0
-    total_count = len(energy_list)
-    native_mfe = float(energy_list[0])
-    for MFE in energy_list:
-        if float(MFE) < float(native_mfe):
-            below_native += 1
-    return float(float(below_native) / float(total_count))
+    """Fraction of ALL r+1 energies below the native one (ScanFoldFunctions.py:727-738); `randomizations` is unused upstream too."""
+    below, total = count_below_native(energy_list)
+    return float(below) / float(total)
 
 
 def zscore_function(energy_list, randomizations):
-    sd = statistics.stdev(energy_list)
-    native_mfe = energy_list[0]
-    scrambled_mean_mfe = statistics.mean(energy_list[1:randomizations])  # drops the last shuffle, as upstream
-    if sd != 0:
-        zscore = (native_mfe - scrambled_mean_mfe) / sd
-    if sd == 0:
-        zscore = float(00.00)
-    return zscore
+    """(native - mean of the shuffles) / sample standard deviation (ScanFoldFunctions.py:741-751).  The quirks are
+    upstream's: the mean runs over energy_list[1:randomizations], which leaves the LAST shuffle out, while the deviation
+    (n-1 denominator, exact `statistics` arithmetic) covers native and all shuffles; a flat list gives 0.0."""
+    spread = statistics.stdev(energy_list)
+    background = statistics.mean(energy_list[1:randomizations])
+    if spread == 0:
+        return float(0)
+    return (energy_list[0] - background) / spread
 
 
 # ----------------------------------------------------------------------------- composition helpers
+_DINUCLEOTIDE_ORDER = tuple(a + b for a in "AUGC" for b in "AUGC")
+
+
 def get_gc_content(frag):
-    frag = str(frag)
-    if 'C' and 'G' in frag:  # sic: upstream's test is effectively `'G' in frag`
-        A_count = frag.count("A") + frag.count("a")
-        G_count = frag.count("G") + frag.count("g")
-        C_count = frag.count("C") + frag.count("c")
-        T_count = frag.count("T") + frag.count("t") + frag.count("U") + frag.count("u")
-        gc_content = round(float(G_count + C_count) / float(A_count + T_count + G_count + C_count), 5)
-    else:
-        gc_content = 0
-    return gc_content
+    """(G + C) / (A + T/U + G + C), either case, 5 decimals (ScanFoldFunctions.py:1023-1036).  Upstream guards the
+    division with `'C' and 'G' in frag`, which Python reads as `'G' in frag`: a window without an upper-case G gets 0."""
+    text = str(frag)
+    if "G" not in text:
+        return 0
+    n = {base: text.count(base) + text.count(base.lower()) for base in "ACGTU"}
+    strong = n["G"] + n["C"]
+    return round(float(strong) / float(n["A"] + n["T"] + n["U"] + strong), 5)
 
 
 def get_dinucleotide_counts(frag):
-    frag = str(frag)
-    frag_list = [frag[i:i + 2] for i in range(0, len(frag))]
-    dinucleotides = ['AA', 'AU', 'AG', 'AC', 'UA', 'UU', 'UG', 'UC', 'GA', 'GU', 'GG', 'GC', 'CA', 'CU', 'CG', 'CC']
-    return [frag_list.count(d) for d in dinucleotides]
+    """Occurrences of the 16 dinucleotides at every offset, in upstream's order AA AU AG AC UA .. CC
+    (ScanFoldFunctions.py:1079-1094)."""
+    text = str(frag)
+    seen = {}
+    for k in range(len(text) - 1):
+        seen[text[k:k + 2]] = seen.get(text[k:k + 2], 0) + 1
+    return [seen.get(d, 0) for d in _DINUCLEOTIDE_ORDER]

@@ -17,24 +17,17 @@ from .functions import dinuclShuffle, multiprocessing, randomizer  # noqa: F401 
 
 
 def pscore_function(energy_list, randomizations):
-    below_native = 0
-    total_count = len(energy_list)
-    native_mfe = float(energy_list[0])
-    for MFE in energy_list:
-        if float(MFE) < float(native_mfe):
-            below_native += 1
-    return float(float(below_native) / float(total_count))
+    """Fraction of all r+1 energies below the native one (ScanFold-Scan.py:218-229)."""
+    below, total = _sff.count_below_native(energy_list)
+    return float(below) / float(total)
 
 
 def zscore_function(energy_list, randomizations):
-    sd = np.std(energy_list)
-    native_mfe = energy_list[0]
-    scrambled_mean_mfe = np.mean(energy_list[1:randomizations])
-    if sd != 0:
-        zscore = (native_mfe - scrambled_mean_mfe) / sd
-    if sd == 0:
-        zscore = "#DIV/0!"
-    return zscore
+    """ScanFold-Scan.py:232-242: population standard deviation (np.std) over native + shuffles, np.mean over
+    energy_list[1:randomizations] (the last shuffle left out), the STRING "#DIV/0!" for a flat list.  One row of the
+    vectorised form below — proven bit-equal to the per-list numpy calls in tests/test_golden_host.py."""
+    z, flat = zscores_rows(np.asarray([list(energy_list)], dtype=np.float64), randomizations)
+    return "#DIV/0!" if flat[0] else z[0]
 
 
 def rna_folder(frag):
@@ -46,16 +39,14 @@ def energies(seq_list):
 
 
 def scramble(text, randomizations, type):
-    frag = str(text)
-    frag_seqs = []
+    """As ScanFoldFunctions.scramble but WITHOUT the T -> U step (ScanFold-Scan.py:266-282): the caller transcribes."""
+    window = str(text)
     if type == "di":
-        for _ in range(randomizations):
-            frag_seqs.append(dinuclShuffle(frag))
-    elif type == "mono":
-        frag_seqs = [randomizer(frag) for _ in range(randomizations)]
-    else:
-        print("Shuffle type not properly designated; please input \"di\" or \"mono\"")
-    return frag_seqs
+        return [dinuclShuffle(window) for _ in range(randomizations)]
+    if type == "mono":
+        return [randomizer(window) for _ in range(randomizations)]
+    print(_sff._SHUFFLE_MESSAGE)
+    return []
 
 
 # ---- row-vectorised forms used by the scan driver; bit-equal to the per-row functions above ----

@@ -31,10 +31,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-WORKLOAD = dict(name="cfg3: 30 kb synthetic RNA, W=120, step=1, 100 di-shuffles", L=30000, seed=3, W=120, step=1,
-                r=100, shuffle="di", shuffle_seed=2026)
+WORKLOADS = {
+    # BASELINE.json configs[2] — the configuration the metric is quoted on; the default
+    "cfg3": dict(name="cfg3: 30 kb synthetic RNA, W=120, step=1, 100 di-shuffles", L=30000, seed=3, W=120, step=1, r=100,
+                 shuffle="di", shuffle_seed=2026, metric="windows/sec (W=120, step=1, 100 shuffles)", verify=64,
+                 counters="profiles/r03/mfe_counters.json"),
+    # BASELINE.json configs[4] on the GPUs given (`--config cfg5`; one step is ~36 s on one MI355X)
+    "cfg5": dict(name="cfg5: 30 kb synthetic RNA, W=200, step=1, 1000 di-shuffles + partition function", L=30000, seed=3,
+                 W=200, step=1, r=1000, shuffle="di", shuffle_seed=2026,
+                 metric="windows/sec (W=200, step=1, 1000 shuffles, partition function)", verify=4,
+                 counters="profiles/r03/cfg5_mfe_counters.json"),
+}
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-VERIFY_WINDOWS = 64
 EXIT_NEED_GPUS = 3
 
 
@@ -53,6 +61,7 @@ def relaunch_under_torchrun(args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__),
            "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup)]
+    cmd += ["--config", args.config]
     if args.no_cpu_baseline:
         cmd.append("--no-cpu-baseline")
     proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
@@ -178,7 +187,7 @@ def reference_python_overhead(seq, W, r, windows=6):
             "windows_per_s_if_folds_were_free": 1.0 / (t_shuffle + t_pool)}
 
 
-def verify_sample(seq, W, step, r, kind, seed, lo, n_loc, en, db, cen, div, n_check=VERIFY_WINDOWS):
+def verify_sample(seq, W, step, r, kind, seed, lo, n_loc, en, db, cen, div, n_check=64, paramset=None):
     """Compare n_check windows of the LAST timed step (device tensors of rank 0's shard) with the oracle: every one
     of the r+1 energies on the oracle's own shuffles, structure, centroid, ensemble diversity.  Returns
     (windows checked, mismatching windows)."""
@@ -186,7 +195,7 @@ def verify_sample(seq, W, step, r, kind, seed, lo, n_loc, en, db, cen, div, n_ch
     from oracle import oracle
     from scanfold_amd import params
     oracle.build()
-    oracle.set_params(params.default_params())
+    oracle.set_params(paramset if paramset is not None else params.default_params())
     n_check = min(n_check, n_loc)
     if n_check <= 0:
         return 0, 0
@@ -208,10 +217,16 @@ def verify_sample(seq, W, step, r, kind, seed, lo, n_loc, en, db, cen, div, n_ch
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", choices=sorted(WORKLOADS), default="cfg3",
+                    help="cfg3 (default, the metric's own configuration) or cfg5 (W=200, r=1000, partition function)")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 2 if args.config == "cfg3" else 1
+    if args.warmup is None:
+        args.warmup = 1 if args.config == "cfg3" else 0
     if args.gpus > 1 and "RANK" not in os.environ:
         return relaunch_under_torchrun(args)
 
@@ -241,7 +256,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
     eng = _lib.Engine(device=local_rank)
 
-    wl = WORKLOAD
+    wl = WORKLOADS[args.config]
     W, step, r = wl["W"], wl["step"], wl["r"]
     kind = _lib.SHUFFLE_DI if wl["shuffle"] == "di" else _lib.SHUFFLE_MONO
     seq = synth_transcript(wl["L"], wl["seed"])
@@ -295,20 +310,23 @@ def main():
         folds_per_launch = folds / max(launches, 1)
         achieved = folds_per_launch * bytes_per_fold / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         traffic, secondary, counters_src = None, None, None
-        for cand in ("profiles/r02/mfe_counters.json", "profiles/pmc_traffic.json"):
+        for cand in (wl["counters"],):
             path = os.path.join(ROOT, cand)
             if os.path.exists(path):
                 try:
                     j = json.load(open(path))
                     traffic = j.get("hbm_bytes_per_launch")
+                    if traffic is None and j.get("hbm_bytes_per_fold") is not None:
+                        traffic = j["hbm_bytes_per_fold"] * folds_per_launch
                     secondary = j.get("secondary")
                     counters_src = cand
                     break
                 except Exception:
                     pass
-        checked, bad = verify_sample(seq, W, step, r, kind, wl["shuffle_seed"], lo, n_loc, en, db, cen, div)
+        checked, bad = verify_sample(seq, W, step, r, kind, wl["shuffle_seed"], lo, n_loc, en, db, cen, div, wl["verify"])
+        algorithmic_bytes = folds_per_launch * bytes_per_fold
         out = {
-            "metric": "windows/sec (W=120, step=1, 100 shuffles)",
+            "metric": wl["metric"],
             "value": value, "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "int32 (int16 LDS storage) energies; f64 partition function",
@@ -318,6 +336,8 @@ def main():
                        "parallelism": "windows sharded over %d rank(s), one all-gather per step" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": algorithmic_bytes,
+                         "traffic_over_algorithmic": (traffic / algorithmic_bytes) if traffic and algorithmic_bytes else None,
                          "traffic_source": counters_src and (counters_src + " (rocprofv3 --pmc passes of this command, "
                                                              "separate runs; not collected inside this run)"),
                          "kernel": "sf_mfe_fast_kernel", "avg_launch_ms": avg_ms, "launches": launches,
@@ -338,8 +358,10 @@ def main():
         if world == 1:
             from scanfold_amd import scan as scanmod
             times, nbytes = [], 0
-            scanmod.scan_record(seq, W, step, r, wl["shuffle"], 37, eng, seed=wl["shuffle_seed"])  # warm-up
-            for _ in range(5):
+            n_e2e = 5 if args.config == "cfg3" else 1
+            if n_e2e > 1:
+                scanmod.scan_record(seq, W, step, r, wl["shuffle"], 37, eng, seed=wl["shuffle_seed"])  # warm-up
+            for _ in range(n_e2e):
                 t0 = time.perf_counter()
                 rows = scanmod.scan_record(seq, W, step, r, wl["shuffle"], 37, eng, seed=wl["shuffle_seed"])
                 times.append(time.perf_counter() - t0)

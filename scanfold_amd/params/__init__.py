@@ -64,6 +64,8 @@ class ParamSet:
     `.temperature`), `.dH` — when the source file had `*_enthalpies` sections — the same record holding enthalpies,
     `.rec37` the free energies at 37 C the set was read with."""
 
+    def_substituted = {}  # section -> number of "DEF" entries the parser filled from the shipped reconstructed table
+
     def __init__(self, rec, source, dH=None, rec37=None, lxc37=None):
         self.rec = rec
         self.source = source
@@ -125,7 +127,7 @@ def _tok_int(t):
     return int(t)
 
 
-def _fill_sections(sections, rec, suffix, source, defaults):
+def _fill_sections(sections, rec, suffix, source, defaults, substituted=None):
     """Fill `rec` from the sections `<name><suffix>` (suffix "" = free energies, "_enthalpies" = enthalpies).
     A "DEF" token keeps the entry of `defaults` (ViennaRNA keeps its compiled-in value there; here the shipped
     default set stands in, which is only right for the entries the two sets share)."""
@@ -140,6 +142,8 @@ def _fill_sections(sections, rec, suffix, source, defaults):
         if (values == _DEF).any():
             if defaults is None:
                 raise ValueError("%s: DEF entries in '%s' but no default set to take them from" % (source, field))
+            if substituted is not None:
+                substituted[field + suffix] = substituted.get(field + suffix, 0) + int((values == _DEF).sum())
             values = np.where(values == _DEF, defaults[field][index], values)
         rec[field][index] = values.reshape(dst.shape)
 
@@ -154,6 +158,8 @@ def _fill_sections(sections, rec, suffix, source, defaults):
     if (core == _DEF).any():
         if defaults is None:
             raise ValueError("%s: DEF entries in 'int22' but no default set to take them from" % source)
+        if substituted is not None:
+            substituted["int22" + suffix] = substituted.get("int22" + suffix, 0) + int((core == _DEF).sum())
         core = np.where(core == _DEF, defaults["int22"][1:7, 1:7, 1:5, 1:5, 1:5, 1:5], core)
     i22 = np.zeros((8, 8, 5, 5, 5, 5), dtype=np.int64)
     i22[1:7, 1:7, 1:5, 1:5, 1:5, 1:5] = core
@@ -214,7 +220,8 @@ def parse_par_text(text, source="<string>", defaults="shipped"):
     missing = [s for s in need if s not in sections]
     if missing:
         raise ValueError("%s: missing sections %s" % (source, missing))
-    _fill_sections(sections, rec, "", source, def_rec)
+    substituted = {}
+    _fill_sections(sections, rec, "", source, def_rec, substituted if defaults == "shipped" else None)
 
     have_dh = all((s + "_enthalpies") in sections for s in table_secs)
     dH = None
@@ -228,6 +235,8 @@ def parse_par_text(text, source="<string>", defaults="shipped"):
             if def_rec is None:
                 raise ValueError("%s: DEF entry for %s but no default set" % (source, field))
             v = int(def_rec[field] if index is None else def_rec[field][index])
+            if defaults == "shipped":
+                substituted[field] = substituted.get(field, 0) + 1
         return v
 
     nin = " ".join(sections["NINIO"]).split()       # m  m_dH  max
@@ -270,7 +279,17 @@ def parse_par_text(text, source="<string>", defaults="shipped"):
                     dH[fe][k] = _tok_int(parts[2])
             k += 1
         rec[fn] = k
-    return ParamSet(rec, source, dH)
+    ps = ParamSet(rec, source, dH)
+    # "DEF" entries of a user's file: ViennaRNA would keep its compiled-in (published) value there, this parser can only
+    # put the shipped RECONSTRUCTED value — a mixed table.  Say so, and let --require-published-params refuse it.
+    ps.def_substituted = substituted
+    if substituted:
+        import sys
+        print("scanfold_amd: WARNING %s has %d DEF entries (sections: %s); they were filled from the RECONSTRUCTED default "
+              "table %s, not from ViennaRNA's compiled-in values" % (source, sum(substituted.values()),
+                                                                     ", ".join(sorted(substituted)), DEFAULT_PAR),
+              file=sys.stderr)
+    return ps
 
 
 def load_par(path):

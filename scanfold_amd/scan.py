@@ -369,7 +369,11 @@ def main(argv=None):
     eng = _lib.get_engine()
     eng.set_max_bp_span(args.span)
     if args.params:
-        eng.load_params(_params.load_par(args.params))
+        user_set = _params.load_par(args.params)
+        if args.require_published_params and user_set.def_substituted:
+            raise SystemExit("--require-published-params: %s has DEF entries in %s; they would be filled from the "
+                             "reconstructed default table" % (args.params, ", ".join(sorted(user_set.def_substituted))))
+        eng.load_params(user_set)
     if rank == 0:
         _params.warn_if_reconstructed(eng.params)
     if world > 1:

@@ -87,6 +87,9 @@ def test_published_file_layout_enthalpies_def_tokens_and_temperature(tmp_path):
     changed = base.rec.copy()
     changed["stack"][1, 2] = 77; changed["stack"][4, 4] = 88; changed["hairpin"][9] = 999
     q = params.parse_par_text(par_text(changed, dH, {"stack": mask, "hairpin": hp}), source="with-DEF.par")
+    # ... and the parser says which sections it filled (a published file with DEF entries becomes a MIXED table here:
+    # --require-published-params refuses it)
+    assert q.def_substituted == {"stack": int(mask.sum()), "hairpin": int(hp.sum())} and not p.def_substituted
     assert q.rec["stack"][1, 2] == base.rec["stack"][1, 2] and q.rec["stack"][4, 4] == base.rec["stack"][4, 4]
     assert q.rec["hairpin"][9] == base.rec["hairpin"][9]
     with pytest.raises(ValueError):

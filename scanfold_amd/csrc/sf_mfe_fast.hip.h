@@ -330,12 +330,25 @@ __device__ __forceinline__ void sf_fast_publish_bn(int16_t *w, const int i0, con
 //   SF_SEC_DML   multiloop split -> dec
 //   SF_SEC_C0    hairpin and generic minima -> e0 (needs HP)
 //   SF_SEC_FIN   c = min(e0, eh, multiloop closing); publishes the cell (needs dec)
-enum { SF_SEC_P1 = 1, SF_SEC_HELP = 2, SF_SEC_DML = 4, SF_SEC_FIN = 8, SF_SEC_C0 = 16, SF_SEC_ALL = 31 };
-template <bool G, int WT, int SEC, bool CH = false, bool FOLD = false>
+//   SF_SEC_PRE   (split steps) the terms the publish step adds to c — they depend on the sequence only — are looked up
+//                BEFORE the exchange barrier, in the shadow of the cell's other LDS waits, and handed to the SF_SEC_FIN
+//                call in `pub` (SF_SEC_POST): the finish after the barrier, which nothing can overlap, loses its three
+//                dependent LDS round trips
+enum { SF_SEC_P1 = 1, SF_SEC_HELP = 2, SF_SEC_DML = 4, SF_SEC_FIN = 8, SF_SEC_C0 = 16, SF_SEC_ALL = 31, SF_SEC_PRE = 32,
+       SF_SEC_POST = 64 };
+struct SfPub {
+  uint32_t a;  // (mismatchI, mismatch1nI) of the reversed pair: what CI and C1N add to c
+  uint32_t b;  // (MLstem + TerminalAU + MLintern, ExtLoop + TerminalAU): what fML and the scratch add to c
+  int tau;     // TerminalAU of the pair: what CB adds
+};
+// UCAP (G code only): compile-time bound on the loop sizes that can exist — d <= 7: 1, d <= 11: 5 — so that the unrolled
+// size tests above it (a scalar compare + branch each, ~110 of them) disappear from the first four steps of a fold, which
+// cost as much as full steps before (profiles/r03/mfe_step_profile.txt).
+template <bool G, int WT, int SEC, bool CH = false, bool FOLD = false, int UCAP = SFD_MAXLOOP>
 __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, const int i, const bool valid,
                                              const int slot2, const int slotd, uint32_t (&HP)[14], int &ovf,
                                              const bool final_fml, const int fnb, int &fpart, int &dec, int &eh, int &e0,
-                                             const int16_t *uni, int &dprev, const int dml_lo = SFD_TURN + 1,
+                                             const int16_t *uni, int &dprev, SfPub &pub, const int dml_lo = SFD_TURN + 1,
                                              const int dml_hi = 1 << 20) {
   // size tables [4][32]: asymmetry, loop initiation, 1xn, bulge (the kernel passes guarded copies on short diagonals)
   // third table: 32-bit pairs (bulge[u], 1xn term of total size u — 32767 for u < 4, where no 1xn loop exists)
@@ -360,6 +373,19 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
   const int um = CH ? d - 2 - (SFD_TURN + 1) : SFD_MAXLOOP;
   const int type = d <= X.maxd ? X.tPair[S[i] * 8 + S[j]] : 0;  // max_bp_span: longer pairs do not exist
   const int si1 = S[i + 1], sj1 = S[j - 1];
+  if ((SEC & SF_SEC_PRE) && type) {
+    const int tr = X.tRPair[S[i] * 8 + S[j]];
+    const int sp1 = S[i - 1], sq1 = S[j + 1];
+    const int tau_in = tr > 2 ? X.TAU : 0;
+    int stem, ext;
+    if (i > 1 && j < W) { stem = X.tM[SF_TIDX(type, sp1, sq1)]; ext = X.tE[SF_TIDX(type, sp1, sq1)]; }
+    else if (i > 1) stem = ext = X.tD5[type * 5 + sp1];
+    else if (j < W) stem = ext = X.tD3[type * 5 + sq1];
+    else stem = ext = 0;
+    pub.a = sf_pk(X.tI[SF_TIDX(tr, sq1, sp1)], X.t1n[SF_TIDX(tr, sq1, sp1)]);
+    pub.b = sf_pk(stem + tau_in + X.MLintern, ext + tau_in);
+    pub.tau = tau_in;
+  }
 // first entry of diagonal dd.  Triangle without diagonals 0..3: sum_{k=4}^{dd-1} (W-k); FOLD: see the file header
 #define FBASE(dd) (FOLD ? ((dd) <= (W + 3) / 2 ? ((dd)-4) * (W - 3) : (W - 1 - (dd)) * (W - 3) + (dd)-3) \
                         : (((dd)-4) * W - ((dd) * ((dd)-1) / 2 - 6)))
@@ -373,7 +399,7 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
   if (G) {
 #pragma unroll
     for (int u = 30; u >= 6; --u) {
-      if (u <= umax) {
+      if (u <= UCAP && u <= umax) {
         const int16_t *row = X.CI + ROW(u) + i0;
         const int e = sfd_min(row[3], row[u - 1]) + SF_UNI(uNIN, u - 4);  // u1 = 2 and u2 = 2
         HSET(u - 4, sfd_min(e, HGET(u - 6)));
@@ -408,11 +434,11 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
       }
     }
   }
-  if (!G || umax >= 5) {
+  if (!G || (UCAP >= 5 && umax >= 5)) {
     const int16_t *row = X.CI + ROW(5) + i0;
     HSET(1, sfd_min(row[3], row[4]) + SF_UNI(uNIN, 1));
   }
-  if (!G || umax >= 4) HSET(0, X.CI[ROW(4) + i0 + 3] + SF_UNI(uNIN, 0));
+  if (!G || (UCAP >= 4 && umax >= 4)) HSET(0, X.CI[ROW(4) + i0 + 3] + SF_UNI(uNIN, 0));
 
   }
 
@@ -438,23 +464,23 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
         const int tb = RP[S[i + 2] * 8 + sj1];  // (i+2, j-1)
         eh = sfd_min(eh, row[2 * 2] + b1 + st[tb]);
       }
-      if (!G || umax >= 2) {  // 1 x 1: (i+2, j-2)
+      if (!G || (UCAP >= 2 && umax >= 2)) {  // 1 x 1: (i+2, j-2)
         const unsigned t2r = RP[S[i + 2] * 8 + S[j - 2]];
         eh = sfd_min(eh, CBAT(ROW(2) + i0 + 2) + X.F->int11T[((tq + t2r) * 5u + si1) * 5u + sj1]);
       }
-      if (!G || umax >= 3) {  // 1 x 2 and 2 x 1
+      if (!G || (UCAP >= 3 && umax >= 3)) {  // 1 x 2 and 2 x 1
         const int16_t *row = X.BN + 2 * (ROW(3) + i0);
         const unsigned ta = RP[S[i + 2] * 8 + S[j - 3]];  // (i+2, j-3), sq1 = S[j-2]
         eh = sfd_min(eh, row[2 * 2] + X.F->int21a[(((tq + ta) * 5u + si1) * 5u + S[j - 2]) * 5u + sj1]);
         const unsigned tb = RP[S[i + 3] * 8 + S[j - 2]];  // (i+3, j-2), sp1 = S[i+2]
         eh = sfd_min(eh, row[2 * 3] + X.F->int21b[(((tb * 8u + type) * 5u + sj1) * 5u + si1) * 5u + S[i + 2]]);
       }
-      if (!G || umax >= 4) {  // 2 x 2: (i+3, j-3)
+      if (!G || (UCAP >= 4 && umax >= 4)) {  // 2 x 2: (i+3, j-3)
         const unsigned t2r = RP[S[i + 3] * 8 + S[j - 3]];
         eh = sfd_min(eh, CBAT(ROW(4) + i0 + 3) +
                              X.F->int22T[((((tq + t2r) * 5u + si1) * 5u + S[i + 2]) * 5u + S[j - 2]) * 5u + sj1]);
       }
-      if (!G || umax >= 5) {  // 2 x 3 and 3 x 2
+      if (!G || (UCAP >= 5 && umax >= 5)) {  // 2 x 3 and 3 x 2
         const int16_t *row = X.BN + 2 * (ROW(5) + i0);
         const int m23 = X.t23[SF_TIDX(type, si1, sj1)] + X.F->L23;
         const int ta = RP[S[i + 3] * 8 + S[j - 4]];  // (i+3, j-4); sp1 = S[i+2], sq1 = S[j-3]
@@ -467,7 +493,7 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
       if (G) {
 #pragma unroll
         for (int u = 2; u <= 30; ++u) {
-          if (u <= umax) {
+          if (u <= UCAP && u <= umax) {
             const int rw = ROW(u) + i0;
             gb = sfd_min(gb, sfd_min(CBAT(rw + 1), CBAT(rw + 1 + u)) + SF_UNI(uBN, 2 * u));
             if (u >= 4) g1 = sfd_min(g1, sfd_min(C1NAT(rw + 2), C1NAT(rw + u)) + SF_UNI(uBN, 2 * u + 1));
@@ -585,14 +611,30 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
     if (type) {
       const int TAU = X.TAU;
       int e;
-      if (G && d <= 7) e = sfd_hairpin(X.D, S, i, j, type);  // sizes 3, 4, 6 may be special loops
-      else e = X.D->hp_init[d - 1] + X.tH[SF_TIDX(type, si1, sj1)];
+      if (G && d <= 7) {
+        // hairpins of 3, 4 and 6 nucleotides may be tabulated special loops (sfd_hairpin's rules).  The key list is
+        // walked in blocks of eight wave-uniform entries without an early exit — scalar loads, one compare and one
+        // select per key — last to first, so that the FIRST matching entry wins as in sfd_special_hairpin.  (The
+        // per-key loop with its exit test cost ~2 k cycles in each of the first two steps of every fold.)
+        const int size = d - 1;
+        e = X.D->hp_init[size] + (size == 3 ? (type > 2 ? TAU : 0) : (int)X.tH[SF_TIDX(type, si1, sj1)]);
+        if (size == 3 || size == 4 || size == 6) {
+          const uint32_t *keys = size == 4 ? X.D->tetra_key : (size == 6 ? X.D->hexa_key : X.D->tri_key);
+          const int32_t *en = size == 4 ? X.D->P.tetra_E : (size == 6 ? X.D->P.hexa_E : X.D->P.tri_E);
+          const int n = size == 4 ? X.D->P.n_tetra : (size == 6 ? X.D->P.n_hexa : X.D->P.n_tri);
+          const uint32_t key = sfd_loop_key(S, i, size + 2);
+          for (int k0 = ((n + 7) & ~7) - 8; k0 >= 0; k0 -= 8) {  // (the arrays hold SF_NSPECIAL = 40 entries; unused keys never match)
+#pragma unroll
+            for (int k = 7; k >= 0; --k) e = keys[k0 + k] == key ? (int)en[k0 + k] : e;
+          }
+        }
+      } else e = X.D->hp_init[d - 1] + X.tH[SF_TIDX(type, si1, sj1)];
       if (!G || umax >= 0) {
         int gg = SF_FAST_BIG;
         if (G) {
 #pragma unroll
           for (int u = 6; u <= 30; ++u)
-            if (u <= umax) gg = sfd_min(gg, HGET(u - 4) + SF_UNI(uIL, u));
+            if (u <= UCAP && u <= umax) gg = sfd_min(gg, HGET(u - 4) + SF_UNI(uIL, u));
         } else {
           // generic minima plus loop initiation, two sizes per packed add / min (size 31 does not exist: its
           // half of HP[13] stays INF)
@@ -627,7 +669,14 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
   // ---- publish the cell ----
   const int rbd = slotd * RW + i0;
   int f = SF_FAST_BIG, cx = SF_INF16;
-  if (type) {
+  if ((SEC & SF_SEC_POST) && type) {
+    X.CI[rbd] = (int16_t)(c + sf_lo(pub.a));
+    const uint32_t bn = sf_pk(c + pub.tau, c + sf_hi(pub.a));  // (CB, C1N)
+    sf_fast_publish_bn<SHIFT>(X.BN + 2 * rbd, i0, bn);
+    if (X.bn_dup && slotd == 0) sf_fast_publish_bn<SHIFT>(X.BN + 2 * (SF_FAST_NR * RW + i0), i0, bn);
+    f = c + sf_lo(pub.b);
+    cx = sfd_min(c + sf_hi(pub.b), SF_INF16);
+  } else if (type) {
     const int tr = X.tRPair[S[i] * 8 + S[j]];
     const int sp1 = S[i - 1], sq1 = S[j + 1];
     const int tau_in = tr > 2 ? X.TAU : 0;
@@ -964,7 +1013,7 @@ __device__ __forceinline__ void sf_fast_exterior(const SfFastCtx &X, const int W
 #define SF_DEFER 1
 #define SF_DEFER_256 1  // the wide kernel trails too (four columns per lane)
 #define SF_DEFER_W200 1
-#define SF_DEFER_ROWS_256 2
+#define SF_DEFER_ROWS_256 3
 template <int NQ>
 struct SfTrail {
   int F[NQ];   // lane l: f3[j+1] for the columns j = l+1+64q (0 until row j+1 has been swept)
@@ -1203,6 +1252,8 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
       const bool valid = (d < W) && (i >= 1) && (i + d <= W);
       int fpart = SF_FAST_BIG;
       int dec = SF_FAST_BIG, eh = SF_FAST_BIG, e0 = SF_FAST_BIG;
+      SfPub pub;
+      pub.a = pub.b = 0; pub.tau = 0;
       // Short diagonals (d < 36): loop sizes above d-6 do not exist.  Instead of testing every size (a branch per
       // size, nothing in flight across it), the cell runs the same straight-line code as on long diagonals with
       // this wave's copy of the size tables in which those sizes cost 32767: their candidates (stale but
@@ -1231,12 +1282,13 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
           if (k < sweep_rows) sf_trail_load<NQ>(X.cg, W, tid & 63, T.row - k, dc[k]);
       }
       if (__ballot(valid)) {
-        if (d0 < SF_FAST_TINY_D0) sf_fast_cell<true, WT, SF_SEC_ALL, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev);
-        else if (d0 < SF_FAST_CHUNK_D0) sf_fast_cell<false, WT, SF_SEC_ALL, true, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev);
-        else if (!split) sf_fast_cell<false, WT, SF_SEC_ALL, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev);
+        if (d0 < 8) sf_fast_cell<true, WT, SF_SEC_ALL, false, FOLD, 1>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev, pub);
+        else if (d0 < SF_FAST_TINY_D0) sf_fast_cell<true, WT, SF_SEC_ALL, false, FOLD, 5>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev, pub);
+        else if (d0 < SF_FAST_CHUNK_D0) sf_fast_cell<false, WT, SF_SEC_ALL, true, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev, pub);
+        else if (!split) sf_fast_cell<false, WT, SF_SEC_ALL, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev, pub);
         else if (!helper) {
-          if (SHARE) sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_DML, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev, SFD_TURN + 1, dml_cut - 1);
-          else sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_DML, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev);
+          if (SHARE) sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_DML | SF_SEC_PRE, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev, pub, SFD_TURN + 1, dml_cut - 1);
+          else sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_DML | SF_SEC_PRE, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev, pub);
         } else if (MERGE) {
           // Merged helper (W <= 128).  ONE helper wave serves both diagonals of the step: it works on the list of the
           // cells of d0 and d0+1 that can pair (build_list above; 3 of 8 cells, so ordinary sequences fit wave 1's 64
@@ -1256,7 +1308,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
             const int sd1 = sd0 + 1 >= SF_FAST_NR ? 0 : sd0 + 1;
             SfFastCtx Xh = X;
             Xh.BN = X.BN + 2 * g * (W - 4);
-            sf_fast_cell<false, WT, SF_SEC_HELP, false, FOLD>(Xh, d0 + g, iC, vC, s2, sd0, H, ovf, false, fnb, fpart, dec, eh, e0, uni, dprev);
+            sf_fast_cell<false, WT, SF_SEC_HELP, false, FOLD>(Xh, d0 + g, iC, vC, s2, sd0, H, ovf, false, fnb, fpart, dec, eh, e0, uni, dprev, pub);
             if (vC) X.BN[2 * ((g ? sd1 : sd0) * (W - 4) + iC - 1)] = (int16_t)sfd_min(eh, 32000);
           }
         } else {
@@ -1264,13 +1316,13 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
           // step, and rewritten by nobody but the cell's own lane): eh in the CB half of its word, its part of the
           // multiloop split in its CI entry
           if (SHARE) {
-            sf_fast_cell<false, WT, SF_SEC_HELP | SF_SEC_DML, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev, dml_cut);
+            sf_fast_cell<false, WT, SF_SEC_HELP | SF_SEC_DML, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev, pub, dml_cut);
             if (valid) {
               X.BN[2 * (slotd * (W - 4) + i - 1)] = (int16_t)sfd_min(eh, 32000);
               X.CI[slotd * (W - 4) + i - 1] = (int16_t)sfd_min(dec, 32000);
             }
           } else {
-            sf_fast_cell<false, WT, SF_SEC_HELP, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev);
+            sf_fast_cell<false, WT, SF_SEC_HELP, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev, pub);
             if (valid) X.BN[2 * (slotd * (W - 4) + i - 1)] = (int16_t)sfd_min(eh, 32000);
           }
         }
@@ -1285,7 +1337,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
             eh = X.BN[2 * (slotd * (W - 4) + i - 1)];
             if (SHARE) dec = sfd_min(dec, (int)X.CI[slotd * (W - 4) + i - 1]);
           }
-          sf_fast_cell<false, WT, SF_SEC_FIN, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev);
+          sf_fast_cell<false, WT, SF_SEC_FIN | SF_SEC_POST, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev, pub);
         }
       }
       __syncthreads();

@@ -231,7 +231,7 @@ int launch_pf(const uint8_t *d_seqs, int n, int row_stride, int W, double *d_dG,
       }
     }
     sf_pf_lds_launch(grid, W, share != nullptr, st, d_seqs, n, row_stride, W, (const SfDevParams *)g.dP, (const SfDevParamsPF *)g.dX,
-                     d_dG, d_mbd, d_cen, d_cd, d_tr, L, win0, step, run_len, share);
+                     d_dG, d_mbd, d_cen, d_cd, d_tr, L, win0, step, run_len, share, (const char *)nullptr, (int *)nullptr);
   } else if (W >= 16 && W <= SF_PFF_MAXW && !g.force_full) {
     const int pf_blocks = g.n_cu * g.pf_blocks_per_cu;
     grid = n < pf_blocks ? n : pf_blocks;
@@ -303,14 +303,17 @@ struct ProfPair {
   }
 };
 
+// d_cons / d_sc: every fold has its own hard constraint / Deigan pseudo-energies (row k of each; trace_stride 1): the
+// constrained native windows of sf_fold_constrained, on the LDS kernel where it applies (W <= 250), else the general one
 int launch_mfe(const uint8_t *d_seqs, int n, int W, int32_t *d_out, hipStream_t st, int trace_stride = 1,
-               char *d_db = nullptr) {
+               char *d_db = nullptr, const char *d_cons = nullptr, const int32_t *d_sc = nullptr) {
   if (n <= 0) return SF_OK;
   ProfPair prof;
   int rc = SF_OK;
-  if (g.force_full || !g.fast_ok || !sf_fast_w_supported(W)) {
+  const bool hc = d_cons || d_sc;
+  if (g.force_full || !g.fast_ok || !sf_fast_w_supported(W) || (hc && (W > 250 || trace_stride != 1))) {
     if ((rc = prof.begin(st))) return rc;
-    rc = launch_full(d_seqs, nullptr, nullptr, n, 1, 1, W, d_out, d_db, d_db ? trace_stride : 0, st);
+    rc = launch_full(d_seqs, nullptr, nullptr, n, 1, 1, W, d_out, d_db, d_db ? trace_stride : 0, st, d_cons, d_sc);
     if (rc) return rc;
     if ((rc = prof.end(st))) return rc;
   } else {
@@ -320,18 +323,23 @@ int launch_mfe(const uint8_t *d_seqs, int n, int W, int32_t *d_out, hipStream_t 
     int *d_cnt = (int *)g.ovf.p, *d_work = d_cnt + 1, *d_list = d_cnt + 2;
     int grid = 0, threads = 0;
     size_t lds = 0, scratch_bytes = 0;
-    sf_fast_geometry(W, g.n_cu, n, &grid, &threads, &lds, &scratch_bytes);
+    sf_fast_geometry(W, g.n_cu, n, &grid, &threads, &lds, &scratch_bytes, hc);
     HIPCHK(hipMemsetAsync(d_cnt, 0, 2 * sizeof(int), st));
     rc = ensure(g.fast_scratch, scratch_bytes);
     if (rc) return rc;
     if ((rc = prof.begin(st))) return rc;
-    sf_fast_launch(grid, threads, lds, st, d_seqs, n, W, (const SfDevParams *)g.dP, (const SfFastParams *)g.dF,
+    if (hc)
+      sf_fast_launch_hc(grid, threads, lds, st, d_seqs, n, W, (const SfDevParams *)g.dP, (const SfFastParams *)g.dF,
+                        (int16_t *)g.fast_scratch.p, d_out, d_cnt, d_list, trace_stride, d_db, (int *)g.status.p, d_work,
+                        d_cons, d_sc);
+    else
+      sf_fast_launch(grid, threads, lds, st, d_seqs, n, W, (const SfDevParams *)g.dP, (const SfFastParams *)g.dF,
                      (int16_t *)g.fast_scratch.p, d_out, d_cnt, d_list, trace_stride, d_db, (int *)g.status.p,
-                     d_work);
+                     d_work, (const char *)nullptr, (const int32_t *)nullptr);
     HIPCHK(hipGetLastError());
     if ((rc = prof.end(st))) return rc;
-    // folds that left the int16 range are redone exactly
-    rc = launch_full(d_seqs, d_list, d_cnt, n, 1, 1, W, d_out, d_db, d_db ? trace_stride : 0, st);
+    // folds that left the int16 range (or hold a forced pair of non-complementary bases) are redone exactly
+    rc = launch_full(d_seqs, d_list, d_cnt, n, 1, 1, W, d_out, d_db, d_db ? trace_stride : 0, st, d_cons, d_sc);
   }
   if (g.prof_on) {
     g.prof_launches++;
@@ -521,10 +529,36 @@ int sf_pf_batch(const uint8_t *seqs, int n, int W, double *ens_dG, double *mbd, 
   return SF_OK;
 }
 
+// Host-side look at the constraint rows before anything is launched.  Returns SF_ERR_CONSTRAINT for unbalanced brackets (ViennaRNA
+// aborts there); *noncanonical = some bracket pair joins two bases that cannot pair (a "type 7" pair: only the general
+// kernels carry its table rows).
+static int scan_constraints(const uint8_t *seqs, const char *cons, int n, int W, bool *noncanonical) {
+  static const uint8_t can[5][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 1}, {0, 0, 0, 1, 0}, {0, 0, 1, 0, 1}, {0, 1, 0, 1, 0}};  // N A C G U
+  std::vector<int> stack((size_t)W + 1);
+  *noncanonical = false;
+  for (int k = 0; k < n; k++) {
+    const char *c = cons + (size_t)k * W;
+    const uint8_t *s = seqs + (size_t)k * W;
+    int sp = 0;
+    for (int i = 0; i < W; i++) {
+      if (c[i] == '(') stack[sp++] = i;
+      else if (c[i] == ')') {
+        if (sp == 0) return SF_ERR_CONSTRAINT;
+        const int o = stack[--sp];
+        if (!can[sf_encode_nt(s[o])][sf_encode_nt(s[i])]) *noncanonical = true;
+      }
+    }
+    if (sp) return SF_ERR_CONSTRAINT;
+  }
+  return SF_OK;
+}
+
 // fc.hc_add_from_db(window_constraints) / fc.sc_add_SHAPE_deigan(...) followed by fc.mfe(), fc.pf(), fc.centroid(),
-// fc.mean_bp_distance() on n windows (ScanFold-Scan.py:405-418; ScanFold.py:508-544): the general int32 / FP64 kernels
-// with the window's constraint applied where they compute a pair type.  Only native windows come here — the
-// reference folds its shuffles unconstrained — so the LDS kernels of the hot path are not involved.
+// fc.mean_bp_distance() on n windows (ScanFold-Scan.py:405-418; ScanFold.py:508-544).  Only native windows come here — the
+// reference folds its shuffles unconstrained.  The window's constraint is applied where a kernel makes a
+// cell's pair type: in the LDS kernels of the hot path (sf_mfe_fast_kernel / sf_pf_lds_kernel, HC instantiations) where
+// they apply, else — W beyond their range, a bracket pair of non-complementary bases, sf_set_kernel_mode(1) — in the general
+// int32 / FP64 kernels.
 int sf_fold_constrained(const uint8_t *seqs, int n, int W, const char *cons, const int32_t *sc_stack_dcal, unsigned flags,
                         int32_t *mfe_out, char *db_out, double *ens_dG, double *mbd, char *centroid, double *cdist) {
   int rc = check_ready();
@@ -532,6 +566,8 @@ int sf_fold_constrained(const uint8_t *seqs, int n, int W, const char *cons, con
   if (n < 0 || W < 1 || W > SF_MAX_W || (n > 0 && !seqs)) return SF_ERR_BAD_ARG;
   if (n == 0) return SF_OK;
   const bool want_mfe = !(flags & SF_FOLD_NO_MFE), want_pf = !(flags & SF_FOLD_NO_PF);
+  bool noncanonical = false;
+  if (cons && (rc = scan_constraints(seqs, cons, n, W, &noncanonical))) return rc;
   if ((rc = ensure(g.seqs, (size_t)n * W))) return rc;
   HIPCHK(hipMemcpyAsync(g.seqs.p, seqs, (size_t)n * W, hipMemcpyHostToDevice, g.stream));
   const char *d_cons = nullptr;
@@ -549,9 +585,14 @@ int sf_fold_constrained(const uint8_t *seqs, int n, int W, const char *cons, con
   if (want_mfe) {
     if ((rc = ensure(g.energies, (size_t)n * sizeof(int32_t)))) return rc;
     if ((rc = ensure(g.db, (size_t)n * (W + 1)))) return rc;
-    if ((rc = launch_full((const uint8_t *)g.seqs.p, nullptr, nullptr, n, 1, 1, W, (int32_t *)g.energies.p,
-                          db_out ? (char *)g.db.p : nullptr, 0, g.stream, d_cons, d_sc)))
-      return rc;
+    // (the LDS kernel with the per-fold constraint where it applies; every fold traced: the structure is the point)
+    if (noncanonical || !(d_cons || d_sc))
+      rc = (d_cons || d_sc) ? launch_full((const uint8_t *)g.seqs.p, nullptr, nullptr, n, 1, 1, W, (int32_t *)g.energies.p,
+                                          (char *)g.db.p, 0, g.stream, d_cons, d_sc)
+                            : launch_mfe((const uint8_t *)g.seqs.p, n, W, (int32_t *)g.energies.p, g.stream, 1, (char *)g.db.p);
+    else
+      rc = launch_mfe((const uint8_t *)g.seqs.p, n, W, (int32_t *)g.energies.p, g.stream, 1, (char *)g.db.p, d_cons, d_sc);
+    if (rc) return rc;
     if (mfe_out)
       HIPCHK(hipMemcpyAsync(mfe_out, g.energies.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, g.stream));
     if (db_out) HIPCHK(hipMemcpyAsync(db_out, g.db.p, (size_t)n * (W + 1), hipMemcpyDeviceToHost, g.stream));
@@ -560,11 +601,21 @@ int sf_fold_constrained(const uint8_t *seqs, int n, int W, const char *cons, con
     int grid = n < max_resident_blocks() ? n : max_resident_blocks();
     if ((rc = ensure(g.dbl, (size_t)n * 3 * sizeof(double)))) return rc;
     if ((rc = ensure(g.cen, (size_t)n * (W + 1)))) return rc;
-    if ((rc = ensure(g.pf_scratch, (size_t)grid * SF_PF_SCRATCH_DOUBLES(W) * sizeof(double)))) return rc;
     double *d_dG = (double *)g.dbl.p, *d_mbd = d_dG + n, *d_cd = d_mbd + n;
-    SF_LAUNCH(sf_pf_kernel, grid, block_threads(W), 0, g.stream, (const uint8_t *)g.seqs.p, n, 1, W,
-              (const SfDevParams *)g.dP, (const SfDevParamsPF *)g.dX, (double *)g.pf_scratch.p, d_dG, d_mbd,
-              (char *)g.cen.p, d_cd, d_cons, (int *)g.status.p);
+    if (!d_cons) {  // (SHAPE data alone do not touch the partition function: the plain kernels)
+      if ((rc = launch_pf((const uint8_t *)g.seqs.p, n, 1, W, d_dG, d_mbd, (char *)g.cen.p, d_cd, g.stream))) return rc;
+    } else if (!noncanonical && !g.force_full && g.pf_kernel == 0 && sf_pfl_supported(W) &&
+               sf_pfl_lds_bytes(W, true) <= SF_PFL_LDS_LIMIT) {
+      grid = n < g.n_cu ? n : g.n_cu;  // every table of a fold in the LDS of one CU
+      sf_pf_lds_launch_hc(grid, W, g.stream, (const uint8_t *)g.seqs.p, n, 1, W, (const SfDevParams *)g.dP,
+                          (const SfDevParamsPF *)g.dX, d_dG, d_mbd, (char *)g.cen.p, d_cd, (const uint8_t *)nullptr, 0, 0, 1, 1,
+                          (double *)nullptr, d_cons, (int *)g.status.p);
+    } else {
+      if ((rc = ensure(g.pf_scratch, (size_t)grid * SF_PF_SCRATCH_DOUBLES(W) * sizeof(double)))) return rc;
+      SF_LAUNCH(sf_pf_kernel, grid, block_threads(W), 0, g.stream, (const uint8_t *)g.seqs.p, n, 1, W,
+                (const SfDevParams *)g.dP, (const SfDevParamsPF *)g.dX, (double *)g.pf_scratch.p, d_dG, d_mbd,
+                (char *)g.cen.p, d_cd, d_cons, (int *)g.status.p);
+    }
     HIPCHK(hipGetLastError());
     if (ens_dG) HIPCHK(hipMemcpyAsync(ens_dG, d_dG, n * sizeof(double), hipMemcpyDeviceToHost, g.stream));
     if (mbd) HIPCHK(hipMemcpyAsync(mbd, d_mbd, n * sizeof(double), hipMemcpyDeviceToHost, g.stream));

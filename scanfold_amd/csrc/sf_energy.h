@@ -190,6 +190,45 @@ __device__ __forceinline__ int sf_hc_type(const SfHc &h, int t, int i, int j, bo
   return t;
 }
 
+// The same for the LDS-resident kernels, whose windows are at most 250 nucleotides: bracket partner and enclosing pair fit a
+// byte each (LDS is what those kernels run out of).  No separate parse stack: the open positions are chained through their
+// own `partner` entries until they close.
+struct SfHc8 {
+  const char *c;           // 1-based (c[1..W]); null: no constraint
+  const uint8_t *partner;  // 0: none
+  const uint8_t *encl;     // 0: none
+};
+// c[1..W] filled by the caller; returns 0 if the brackets balance
+__device__ inline int sf_hc_parse8(int W, const char *c, uint8_t *partner, uint8_t *encl) {
+  int top = 0, bad = 0;
+  for (int i = 1; i <= W; i++) partner[i] = 0;
+  for (int i = 1; i <= W && !bad; i++) {
+    const char ch = c[i];
+    if (ch == ')') {
+      if (top == 0) { bad = 1; break; }
+      const int o = top;
+      top = partner[o];  // the open position below it
+      partner[o] = (uint8_t)i;
+      partner[i] = (uint8_t)o;
+    }
+    encl[i] = (uint8_t)top;
+    if (ch == '(') {
+      partner[i] = (uint8_t)top;  // (chain; overwritten when the pair closes)
+      top = i;
+    }
+  }
+  return bad || top != 0;
+}
+__device__ __forceinline__ int sf_hc_type8(const SfHc8 &h, int t, int i, int j, bool span_ok) {
+  if (!h.c) return t;
+  const int pi = h.partner[i], pj = h.partner[j];
+  if (pi || pj) return (pi == j && span_ok) ? (t ? t : 7) : 0;
+  const char ci = h.c[i], cj = h.c[j];
+  if (ci == 'x' || cj == 'x' || ci == '>' || cj == '<') return 0;
+  if (h.encl[i] != h.encl[j]) return 0;  // would cross a bracket pair
+  return t;
+}
+
 // ASCII or code -> code 0..4 (N,A,C,G,U)
 __device__ __host__ inline uint8_t sf_encode_nt(uint8_t c) {
   if (c <= 4) return c;

@@ -172,6 +172,7 @@ struct SfFastLayout {
   int tri;  // int16 entries of the fML triangle (diagonals >= 4)
   int off_ci, off_c1n, off_cb, off_dml, off_list, off_next, off_tab, off_red, off_flag, off_S;
   int off_guard;  // per-wave copies of the size tables for the short diagonals (sf_fast_guard_tables)
+  int off_hc;     // (hc layouts) constraint characters | partners | enclosing pairs | int16 pseudo-energies
   int total;
 };
 // int16 entries: mismatch23 rows 0..6 (175), five more mismatch tables rows 1..6 (150 each), stack (64; holds
@@ -179,7 +180,9 @@ struct SfFastLayout {
 // mismatch23 minus the terminal penalty of its type, rows 0..6 (175), one pad
 #define SF_FAST_TAB_OLD (175 + 5 * 150 + 64 + 40 + 40 + 32 + 1 + 4 * 32)
 #define SF_FAST_TAB_BYTES ((SF_FAST_TAB_OLD + 32 + 175 + 1) * 2)
-static inline __host__ __device__ SfFastLayout sf_fast_layout(int W) {
+// hc: the instantiation for constrained folds (sf_fold_constrained) also carries the window's constraint — characters,
+// bracket partners, enclosing pairs: a byte each — and its Deigan pseudo-energies (int16) for positions 0..W+1
+static inline __host__ __device__ SfFastLayout sf_fast_layout(int W, bool hc = false) {
   SfFastLayout L;
   int tri = (W - 4) * W - (W * (W - 1) / 2 - 6);  // sum_{d=4}^{W-1} (W-d)
   if (W > 128) tri = ((W + 3) / 2 - 3) * (W - 3);  // FOLD: (H-3) rows of S = W-3 entries (same area)
@@ -209,6 +212,8 @@ static inline __host__ __device__ SfFastLayout sf_fast_layout(int W) {
   L.off_flag = o; o += 4;
   L.off_next = o; o += 4;  // index of the workgroup's next fold (dynamic distribution)
   L.off_S = o; o += (W + 2 + 3) & ~3;
+  L.off_hc = o;
+  if (hc) o += ((5 * (W + 2) + 3) & ~3);
   // 256 bytes per wave, needed while d < 36 only: from W = 96 on they lie in the end of the fML triangle, whose
   // last 45 diagonals (>= 2 kB from W = 96 on, first written at d = W-45 >= 51) are still unused by then
   const int guard_bytes = (W <= 128 ? 4 : 8) * 256;
@@ -237,6 +242,8 @@ struct SfFastCtx {
   int fold;     // 1: the fML area is the folded rectangle (W > 128), 0: the triangle
   int bn_dup;   // 1: BN has a row NR that mirrors row 0 (merged helper)
   int maxd;     // largest allowed j - i of a base pair (max_bp_span - 1)
+  SfHc8 hc;     // the fold's hard constraint (hc.c null: none)
+  const int16_t *sc;  // its Deigan pseudo-energies, 1-based, or null
   const int16_t *uNIN, *uIL, *uL1N, *uBUL;  // size-dependent terms, LDS copies (uniform reads)
   int16_t *BN;  // sf_mfe_fast_kernel: the bulge and 1xn rolling tables interleaved, entry x = (CB[x], C1N[x]) in one
                 // 32-bit word (CB / C1N above stay null there); uNIN = [NIN 32][IL 32][(BUL[u], L1N[u-1]) 32 pairs]
@@ -371,7 +378,15 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
   // CH (short diagonals, 12 <= d < 36, straight-line code with guarded size tables): whole batches of sizes above
   // the wave-uniform limit are skipped — the kernel is close to VALU-bound, work on sizes that cannot exist is not free
   const int um = CH ? d - 2 - (SFD_TURN + 1) : SFD_MAXLOOP;
-  const int type = d <= X.maxd ? X.tPair[S[i] * 8 + S[j]] : 0;  // max_bp_span: longer pairs do not exist
+  int type = d <= X.maxd ? X.tPair[S[i] * 8 + S[j]] : 0;  // max_bp_span: longer pairs do not exist
+  if (X.hc.c) {
+    // hard constraint of the window (fc.hc_add_from_db, ScanFold-Scan.py:405-410): applied where the pair type is made.
+    // The pairs enclosed by (i,j) keep their sequence-only types in the candidate look-ups: a pair the constraint
+    // forbids has c = "none" and never wins.  A bracket pair of non-complementary bases (type 7) has no row in the int16
+    // tables: such a fold goes to the exact kernel through the overflow list (the host routes those windows there anyway).
+    type = sf_hc_type8(X.hc, type, i, j, d <= X.maxd);
+    if (type == 7) { type = 0; ovf = 1; }
+  }
   const int si1 = S[i + 1], sj1 = S[j - 1];
   if ((SEC & SF_SEC_PRE) && type) {
     const int tr = X.tRPair[S[i] * 8 + S[j]];
@@ -452,9 +467,10 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
       // (every table below already carries "- TerminalAU(inner pair)": CB holds c + that term, see SfFastParams)
       const uint8_t *RP = X.tRPair;
       const unsigned tq = (unsigned)type * 8u;
-      {  // stack
+      {  // stack (+ the Deigan pseudo-energies of its four nucleotides: fc.sc_add_SHAPE_deigan, ScanFold.py:533-539)
         const int t2r = RP[si1 * 8 + sj1];
-        eh = sfd_min(eh, CBAT(ROW(0) + i0 + 1) + st[t2r]);
+        const int sc4 = X.sc ? X.sc[i] + X.sc[i + 1] + X.sc[j - 1] + X.sc[j] : 0;
+        eh = sfd_min(eh, CBAT(ROW(0) + i0 + 1) + st[t2r] + sc4);
       }
       if (!G || umax >= 1) {  // one-nucleotide bulges keep the stack
         const int b1 = SF_UNI(uBN, 2);
@@ -846,7 +862,8 @@ __device__ inline int sf_fast_traceback(const SfFastCtx &X, const int32_t *f5s, 
             const int p = i + 1 + u1, q = j - 1 - u2;
             const int t2 = TPAIR(p, q);
             if (t2)
-              ok = (cij == sfd_intloop(D, u1, u2, type, sfd_rtype(t2), S[i + 1], S[j - 1], S[p - 1], S[q + 1]) + TC(p, q));
+              ok = (cij == sfd_intloop(D, u1, u2, type, sfd_rtype(t2), S[i + 1], S[j - 1], S[p - 1], S[q + 1]) + TC(p, q) +
+                           ((X.sc && (u1 | u2) == 0) ? X.sc[i] + X.sc[i + 1] + X.sc[j - 1] + X.sc[j] : 0));
           }
           const unsigned long long m = __ballot(ok);
           if (m) found = base + (__ffsll(m) - 1);
@@ -1068,20 +1085,29 @@ __device__ __forceinline__ void sf_trail_result(const SfTrail<NQ> &T, const int 
 
 
 // MG: the merged helper (narrow kernel, W < SF_HELP_MERGE_MAXW; the launcher picks the instantiation)
-template <int NG, int WT, bool MG = false>
+// HC: every fold has its own hard constraint (cons_rows + seq * W, W characters) and / or Deigan pseudo-energies
+// (sc_rows + seq * W, dcal/mol per nucleotide): the constrained native windows of `-c` / `--react` (sf_fold_constrained)
+template <int NG, int WT, bool MG = false, bool HC = false>
 __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_kernel(const uint8_t *__restrict__ seqs, int n, int Wrt,
                                                              const SfDevParams *__restrict__ D,
                                                              const SfFastParams *__restrict__ F,
                                                              int16_t *__restrict__ cg_all, int32_t *__restrict__ out,
                                                              int *__restrict__ ovf_cnt, int *__restrict__ ovf_list,
                                                              int trace_stride, char *__restrict__ db_out,
-                                                             int *__restrict__ status, int *__restrict__ work_ctr) {
+                                                             int *__restrict__ status, int *__restrict__ work_ctr,
+                                                             const char *__restrict__ cons_rows,
+                                                             const int32_t *__restrict__ sc_rows) {
   constexpr int NT = 2 * NG;
   constexpr bool FOLD = (NG == 256);  // W > 128: fML in the folded rectangle (see the file header)
   const int W = WT ? WT : Wrt;
   SF_DYN_SMEM(smem);
-  const SfFastLayout Lo = sf_fast_layout(W);
+  const SfFastLayout Lo = sf_fast_layout(W, HC);
   SfFastCtx X;
+  char *const hcC = (char *)(smem + Lo.off_hc);
+  uint8_t *const hcP = (uint8_t *)hcC + (W + 2), *const hcE = hcP + (W + 2);
+  int16_t *const scS = (int16_t *)(smem + Lo.off_hc + (((3 * (W + 2)) + 1) & ~1));
+  X.hc.c = (HC && cons_rows) ? hcC : nullptr; X.hc.partner = hcP; X.hc.encl = hcE;
+  X.sc = (HC && sc_rows) ? scS : nullptr;
   X.fML = (int16_t *)smem;
   X.CI = (int16_t *)(smem + Lo.off_ci);
   X.C1N = nullptr; X.CB = nullptr;
@@ -1195,6 +1221,22 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
       fetched = (int)gridDim.x + atomicAdd(work_ctr, 1);
     }
     __syncthreads();
+    if (HC) {
+      // the fold's constraint: copied by everybody, parsed by one thread (unbalanced brackets: reported, nothing folded)
+      if (cons_rows)
+        for (int x = tid; x < W; x += NT) hcC[x + 1] = cons_rows[(size_t)seq * W + x];
+      if (sc_rows)
+        for (int x = tid; x < W; x += NT) scS[x + 1] = (int16_t)sfd_max(sfd_min(sc_rows[(size_t)seq * W + x], 30000), -30000);
+      __syncthreads();
+      if (cons_rows && tid == 0) flag[0] = sf_hc_parse8(W, hcC, hcP, hcE) ? 2 : 0;
+      __syncthreads();
+      if (cons_rows && flag[0] == 2) {
+        if (tid == 0) { atomicOr(status, 2); out[seq] = 0; *next_slot = fetched; }  // (thread 0 holds the next fold's index)
+        __syncthreads();
+        seq = *next_slot;
+        continue;
+      }
+    }
     int next_seq = n;  // (set in the third step; W >= 16 has at least five)
     // a fold whose structure is wanted keeps the 5' -> 3' sweep at its end (the traceback reads f5[])
     const bool trail_this = defer_on && !(db_out && (seq % trace_stride) == 0);
@@ -1408,12 +1450,20 @@ static inline hipError_t sf_fast_configure() {
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void *)sf_mfe_fast_kernel<256, 200>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) return e;
-  return hipFuncSetAttribute((const void *)sf_mfe_fast_kernel<256, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  e = hipFuncSetAttribute((const void *)sf_mfe_fast_kernel<256, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) return e;
+  // the instantiations for constrained folds (generic widths only)
+  e = hipFuncSetAttribute((const void *)sf_mfe_fast_kernel<128, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) return e;
+  e = hipFuncSetAttribute((const void *)sf_mfe_fast_kernel<128, 0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute((const void *)sf_mfe_fast_kernel<256, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 // grid / LDS / scratch for n folds of W nt on a chip with n_cu CUs
-static inline void sf_fast_geometry(int W, int n_cu, int n, int *grid, int *threads, size_t *lds, size_t *scratch) {
-  const SfFastLayout L = sf_fast_layout(W);
+static inline void sf_fast_geometry(int W, int n_cu, int n, int *grid, int *threads, size_t *lds, size_t *scratch,
+                                    bool hc = false) {
+  const SfFastLayout L = sf_fast_layout(W, hc);
   const int nt = sf_fast_threads(W);
   int per_cu = (160 * 1024) / L.total;
   // The kernel is compiled for SF_FAST_WAVES_PER_SIMD waves per SIMD (128 VGPRs each): more workgroups than that
@@ -1441,4 +1491,12 @@ static inline void sf_fast_launch(int grid, int threads, size_t lds, hipStream_t
   else if (threads == 256) SF_LAUNCH((sf_mfe_fast_kernel<128, 0>), grid, 256, lds, st, seqs, n, W, args...);
   else if (W == 200) SF_LAUNCH((sf_mfe_fast_kernel<256, 200>), grid, 512, lds, st, seqs, n, W, args...);
   else SF_LAUNCH((sf_mfe_fast_kernel<256, 0>), grid, 512, lds, st, seqs, n, W, args...);
+}
+// constrained folds (per-fold hard constraint / Deigan pseudo-energies; every fold traced)
+template <typename... A>
+static inline void sf_fast_launch_hc(int grid, int threads, size_t lds, hipStream_t st, const uint8_t *seqs, int n, int W,
+                                     A... args) {
+  if (threads == 256 && W < SF_HELP_MERGE_MAXW && SF_HELP_MERGE) SF_LAUNCH((sf_mfe_fast_kernel<128, 0, true, true>), grid, 256, lds, st, seqs, n, W, args...);
+  else if (threads == 256) SF_LAUNCH((sf_mfe_fast_kernel<128, 0, false, true>), grid, 256, lds, st, seqs, n, W, args...);
+  else SF_LAUNCH((sf_mfe_fast_kernel<256, 0, false, true>), grid, 512, lds, st, seqs, n, W, args...);
 }

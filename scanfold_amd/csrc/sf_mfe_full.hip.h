@@ -65,9 +65,11 @@ __global__ void sf_mfe_full_kernel(const uint8_t *__restrict__ seqs, const int *
     for (int x = tid; x < 4 * W1 && x < W * W1; x += nthreads) { c[x] = SFD_INF; fML[x] = SFD_INF; DML[x] = SFD_INF; }
     SfHc hc;
     hc.c = cons_rows ? hcC : nullptr; hc.partner = hcP; hc.encl = hcE;
-    if (cons_rows && tid == 0) hcBad = sf_hc_parse(cons_rows + (size_t)k * W, W, hcC, hcP, hcE, hcStk);
+    // (constraint / pseudo-energy rows go by SEQUENCE ROW: with an index list — the folds the int16 kernel hands back —
+    // item k is row idx_list[k]; without one row == k * row_stride, and constrained callers use row_stride 1)
+    if (cons_rows && tid == 0) hcBad = sf_hc_parse(cons_rows + (size_t)row * W, W, hcC, hcP, hcE, hcStk);
     if (sc_rows)
-      for (int x = tid; x < W; x += nthreads) scS[x + 1] = sc_rows[(size_t)k * W + x];
+      for (int x = tid; x < W; x += nthreads) scS[x + 1] = sc_rows[(size_t)row * W + x];
     __syncthreads();
     if (cons_rows && hcBad) {  // unbalanced brackets: report, fold nothing (ViennaRNA aborts the process here)
       if (tid == 0) {

@@ -56,10 +56,12 @@
 #define SF_PK_CODE(p) (((p) >> 12) & 31)
 #define SF_PK_NT(p) ((p) >> 20)
 
-__host__ __device__ inline size_t sf_pfl_lds_bytes(int W) {
+// hc: the instantiation for constrained folds also holds the window's constraint (characters, bracket partners, enclosing
+// pairs: a byte each for positions 0..W+1)
+__host__ __device__ inline size_t sf_pfl_lds_bytes(int W, bool hc = false) {
   const size_t NC = (size_t)(W - 4) * (W - 3) / 2, RP = W + 2 * SF_PFL_PAD, VW = W + 8;
   const size_t dbl = 2 * NC + 12 * RP + 3 * 625 + 2 * VW + 8 + 6 * VW + 7 * VW + (W + 2) + (W + 3) + 16 + 4 * 32 + (W + 8);
-  return dbl * sizeof(double) + 2 * (size_t)(W + 2) * sizeof(int) + (size_t)(W + 8) + 64;
+  return dbl * sizeof(double) + 2 * (size_t)(W + 2) * sizeof(int) + (size_t)(W + 8) + 64 + (hc ? (size_t)((3 * (W + 2) + 7) & ~7) : 0);
 }
 // doubles per workgroup of the shared-inside state: qb, qm, derived buffers, qm1, 27 registers per centre slot
 #define SF_PFL_SHARE_DOUBLES(W) ((size_t)((W)-4) * ((W)-3) + 12 * ((W) + 2 * SF_PFL_PAD) + 2 * ((W) + 8) + 8 + SF_PFL_SLOTS * 27)
@@ -80,7 +82,11 @@ __device__ __forceinline__ double sf_lane_read_f64(const double v, const int l) 
 }
 
 
-template <int WT, bool SH>
+// HC: fold k has its own hard constraint, W characters at cons_rows + k * row_stride * W (fc.hc_add_from_db, ScanFold-Scan.py:
+// 405-410; sf_fold_constrained): applied where a cell's own pair type is made, inside and outside.  Unbalanced brackets set
+// bit 1 of *status.  The caller keeps windows with a bracket pair of non-complementary bases (type 7) away from this kernel
+// (its mismatch-weight tables are built from sequence-only pair types).
+template <int WT, bool SH, bool HC = false>
 __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__restrict__ seqs, int n, int row_stride,
                                                               int Wrt, const SfDevParams *__restrict__ D,
                                                               const SfDevParamsPF *__restrict__ X,
@@ -89,7 +95,9 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
                                                               char *__restrict__ centroid,
                                                               double *__restrict__ centroid_dist,
                                                               const uint8_t *__restrict__ tr, int L, int win0,
-                                                              int step, int run_len, double *__restrict__ share) {
+                                                              int step, int run_len, double *__restrict__ share,
+                                                              const char *__restrict__ cons_rows,
+                                                              int *__restrict__ status) {
   // SH (native windows of one transcript, `step` nucleotides apart, sf_scan): a workgroup takes RUNS of run_len
   // consecutive windows.  The inside tables of window w+1 are those of window w shifted by `step` rows and columns
   // plus `step` new columns — provided the ends of a window are treated like any other position
@@ -123,6 +131,10 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
   int *BWD = FWD + (W + 2);           // [W+2]  packed code of (S[x], S[x-1])
   uint8_t *S = (uint8_t *)(BWD + (W + 2));  // [W+8]
   uint8_t *PT8 = S + (W + 8);               // [64] pair type of two nucleotide codes
+  char *hcC = (char *)(PT8 + 64);           // (HC) [W+2] constraint characters, then partners, then enclosing pairs
+  uint8_t *hcP = (uint8_t *)hcC + (W + 2), *hcE = hcP + (W + 2);
+  SfHc8 hc;
+  hc.c = (HC && cons_rows) ? hcC : nullptr; hc.partner = hcP; hc.encl = hcE;
 #define COFF(j) ((((j)-5) * ((j)-4)) >> 1)
 #define DOFF(d) (((d)-4) * W - ((((d) * ((d)-1)) >> 1) - 6))
 #define QBC(i, j) QB[COFF(j) + (i)-1]
@@ -130,7 +142,7 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
 #define DERP(kind, col) (DER + ((kind)*4 + ((col)&3)) * RP + SF_PFL_PAD)
 #define PAIR(a, b) PT8[(a)*8 + (b)]
 // pair type of the cell itself: none beyond RNA.md().max_bp_span
-#define OWN(a, b) (((b) - (a)) <= maxd ? PAIR(S[a], S[b]) : 0)
+#define OWN(a, b) sf_hc_type8(hc, (((b) - (a)) <= maxd ? PAIR(S[a], S[b]) : 0), (a), (b), ((b) - (a)) <= maxd)
   const double xTAU = X->TermAU;
   const double xMLbase = X->MLbase;
   const int maxd = D->max_pair_dist;
@@ -159,6 +171,13 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
     __syncthreads();
     for (int x = tid; x < W; x += SF_PFL_NT) S[x + 1] = sf_encode_nt(src[x]);
     if (tid == 0) { S[0] = nbL ? sf_encode_nt(tr[pos - 1]) : 0; S[W + 1] = nbR ? sf_encode_nt(tr[pos + W]) : 0; }
+    if (HC && cons_rows) {
+      for (int x = tid; x < W; x += SF_PFL_NT) hcC[x + 1] = cons_rows[(size_t)fold * row_stride * W + x];
+      __syncthreads();
+      if (tid == 0 && sf_hc_parse8(W, hcC, hcP, hcE)) {  // unbalanced: reported; the fold runs with whatever matched
+        if (status) atomicOr(status, 2);
+      }
+    }
     for (int x = tid; x < 12 * RP; x += SF_PFL_NT) DER[x] = 0.0;
     for (int x = tid; x < 15 * VW + 8; x += SF_PFL_NT) QM1[x] = 0.0;  // QM1, the six R vectors, the partial sums
     __syncthreads();
@@ -703,9 +722,17 @@ static inline hipError_t sf_pfl_configure() {
   if (e != hipSuccess) return e;
   e = hipFuncSetAttribute((const void *)sf_pf_lds_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, SF_PFL_LDS_LIMIT);
   if (e != hipSuccess) return e;
-  return hipFuncSetAttribute((const void *)sf_pf_lds_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SF_PFL_LDS_LIMIT);
+  e = hipFuncSetAttribute((const void *)sf_pf_lds_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SF_PFL_LDS_LIMIT);
+  if (e != hipSuccess) return e;
+  return hipFuncSetAttribute((const void *)sf_pf_lds_kernel<0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SF_PFL_LDS_LIMIT);
 }
 
+// constrained folds: stand-alone folds only (a window's constraint slice changes which cells exist, so consecutive windows
+// do not share their inside tables)
+template <typename... A>
+static inline void sf_pf_lds_launch_hc(int grid, int W, hipStream_t st, A... args) {
+  SF_LAUNCH((sf_pf_lds_kernel<0, false, true>), grid, SF_PFL_NT, sf_pfl_lds_bytes(W, true), st, args...);
+}
 template <typename... A>
 static inline void sf_pf_lds_launch(int grid, int W, bool shared, hipStream_t st, A... args) {
   const size_t lds = sf_pfl_lds_bytes(W);

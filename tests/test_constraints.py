@@ -26,6 +26,20 @@ def random_constraint(rng, n, max_pairs=2):
     return "".join(c)
 
 
+def canonical_constraint(rng, seq, max_pairs=3):
+    """A constraint whose bracket pairs join bases that CAN pair (the LDS kernels take these; a bracket pair of
+    non-complementary bases is a type-7 pair and goes to the general kernels)."""
+    n = len(seq)
+    c = list(rng.choice(list("......x<>|"), n))
+    ok = {("G", "C"), ("C", "G"), ("G", "U"), ("U", "G"), ("A", "U"), ("U", "A")}
+    for _ in range(max_pairs * 8):
+        a = int(rng.integers(0, n - 5))
+        b = int(rng.integers(a + 4, n))
+        if (seq[a], seq[b]) in ok and all(ch not in "()" for ch in c[a:b + 1]) and c.count("(") < max_pairs:
+            c[a], c[b] = "(", ")"
+    return "".join(c)
+
+
 def rseq(rng, n):
     return "".join("ACGU"[k] for k in rng.integers(0, 4, n))
 
@@ -78,17 +92,26 @@ def emul():
     return emul_engine()
 
 
-def test_general_kernels_follow_the_oracle_under_constraints(emul, oracle):
+def test_constrained_kernels_follow_the_oracle(emul, oracle):
+    """sf_fold_constrained in both kernel modes: 0 = the LDS kernels with the constraint at their pair-type seam
+    (sf_mfe_fast_kernel / sf_pf_lds_kernel, HC instantiations; batches with a bracket pair of non-complementary bases and
+    folds that leave the int16 range fall back to the general kernels), 1 = the general int32 / FP64 kernels."""
     emul.load_params(params.default_params())
     rng = np.random.default_rng(5)
     try:
-        for t in range(16):
+        for t in range(24):
             W = int(rng.choice([20, 33, 60, 120]))
             n = 2 if W == 120 else 3
             seqs = [rseq(rng, W) for _ in range(n)]
-            cons = [random_constraint(rng, W, 3) for _ in range(n)]
+            # two batches out of three keep to pairs the LDS kernels' tables hold
+            cons = [canonical_constraint(rng, s, 3) for s in seqs] if t % 3 else [random_constraint(rng, W, 3) for _ in range(n)]
             sc = rng.integers(-60, 40, (n, W)).astype(np.int32) if t % 2 else None
+            emul.set_kernel_mode(1)
+            r1 = emul.fold_constrained(seqs, cons, sc)
+            emul.set_kernel_mode(0)
             r = emul.fold_constrained(seqs, cons, sc)
+            assert r["structure"] == r1["structure"] and (r["mfe"] == r1["mfe"]).all() and r["centroid"] == r1["centroid"]
+            assert np.abs(np.asarray(r["dG"]) - np.asarray(r1["dG"])).max() < 1e-9
             for k in range(n):
                 oracle.set_constraint(cons[k], None if sc is None else sc[k])
                 assert oracle.mfe(seqs[k]) == (r["structure"][k], int(r["mfe"][k])), (seqs[k], cons[k])

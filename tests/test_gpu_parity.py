@@ -454,15 +454,24 @@ def test_scan_step_one_shares_inside_tables(gpu_engine, oracle):
 
 def test_constrained_native_folds_match_oracle(gpu_engine, oracle):
     """sf_fold_constrained (fc.hc_add_from_db / fc.sc_add_SHAPE_deigan, ScanFold-Scan.py:405-418; ScanFold.py:508-544):
-    the general int32 / FP64 kernels under a per-window constraint, 300 windows of W=120 and smaller shapes."""
-    from test_constraints import random_constraint, rseq
+    a per-window constraint at the pair-type seam of the LDS kernels (kernel mode 0: sf_mfe_fast_kernel / sf_pf_lds_kernel, HC
+    instantiations — batches whose bracket pairs can all pair) and of the general int32 / FP64 kernels (mode 1, and batches
+    with a bracket pair of non-complementary bases); 300 windows of W=120 and smaller shapes, both modes equal, both == oracle."""
+    from test_constraints import canonical_constraint, random_constraint, rseq
     rng = np.random.default_rng(77)
     try:
-        for W, n, use_sc in ((120, 300, False), (120, 60, True), (45, 64, True), (200, 12, False)):
+        for W, n, use_sc, canon in ((120, 300, False, True), (120, 300, False, False), (120, 60, True, True), (45, 64, True, True),
+                                    (100, 40, True, False), (200, 12, False, True)):
             seqs = [rseq(rng, W) for _ in range(n)]
-            cons = [random_constraint(rng, W, 4) for _ in range(n)]
+            cons = [canonical_constraint(rng, s, 4) for s in seqs] if canon else [random_constraint(rng, W, 4) for _ in range(n)]
             sc = rng.integers(-60, 40, (n, W)).astype(np.int32) if use_sc else None
+            gpu_engine.set_kernel_mode(1)
+            r1 = gpu_engine.fold_constrained(seqs, cons, sc)
+            gpu_engine.set_kernel_mode(0)
             r = gpu_engine.fold_constrained(seqs, cons, sc)
+            assert r["structure"] == r1["structure"] and (r["mfe"] == r1["mfe"]).all() and r["centroid"] == r1["centroid"]
+            assert np.abs(np.asarray(r["dG"]) - np.asarray(r1["dG"])).max() < PF_TOL
+            assert np.abs(np.asarray(r["mean_bp_dist"]) - np.asarray(r1["mean_bp_dist"])).max() < PF_TOL
             for k in range(0, n, 1 if n <= 64 else 5):
                 oracle.set_constraint(cons[k], None if sc is None else sc[k])
                 assert oracle.mfe(seqs[k]) == (r["structure"][k], int(r["mfe"][k])), (W, k)

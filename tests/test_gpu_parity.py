@@ -291,15 +291,21 @@ def test_bench_instantiation_cfg3_w120_step1_r100_all_outputs(gpu_engine, oracle
 
 
 def test_config5_shape_w200_r1000_slice(gpu_engine, oracle):
-    # BASELINE config 5 shape (W=200, 1000 shuffles, partition function) on a 6-window slice of the 30 kb transcript
+    # BASELINE config 5 shape (W=200, 1000 shuffles, partition function) on a 64-window slice of the 30 kb transcript:
+    # 64 064 folds of 200 nt, every energy, structure, centroid and ensemble diversity.  Reference values: the oracle's
+    # faster twin (oracle/sf_cpu_twin.c, itself checked against the checker in tests/test_oracle.py) for all 64 windows,
+    # the checker itself (oracle/sf_oracle.c) for the first six.
     seq = synth_transcript(30000, 3)
-    W, r, lo, n = 200, 1000, 777, 6
+    W, r, lo, n = 200, 1000, 777, 64
     res = gpu_engine.scan(seq, W, 1, lo, n, r, _lib.SHUFFLE_DI, 99)
     rows = ascii_rows(gpu_engine.shuffle_windows(seq, W, 1, lo, n, r, _lib.SHUFFLE_DI, 99))
-    ref = oracle.scan_windows(rows, n, r)
+    ref = oracle.twin_scan_windows(rows, n, r)
     assert (res["energies"] == ref["energies"]).all()
     assert res["structure"] == ref["structure"] and res["centroid"] == ref["centroid"]
     assert np.abs(res["ens_div"] - ref["ens_div"]).max() < PF_TOL
+    chk = oracle.scan_windows(rows[:6 * (r + 1)], 6, r)
+    assert (res["energies"][:6] == chk["energies"]).all() and res["structure"][:6] == chk["structure"]
+    assert res["centroid"][:6] == chk["centroid"] and np.abs(res["ens_div"][:6] - chk["ens_div"]).max() < PF_TOL
 
 
 def test_edge_shapes(gpu_engine, oracle):

@@ -85,7 +85,9 @@ int sf_pf_batch(const uint8_t *seqs, int n, int W, double *ensemble_dG, double *
  *                  stacked pair it takes part in — MFE and traceback only, as the reference adds SHAPE data after its
  *                  partition function call.
  * Outputs as sf_mfe_trace_batch / sf_pf_batch; any may be NULL.  flags: SF_FOLD_NO_PF, SF_FOLD_NO_MFE.
- * These folds run on the general int32 / FP64 kernels; shuffles are folded unconstrained, as upstream. */
+ * These folds run on the LDS kernels of the hot path with the constraint applied where a cell's pair type is made (W <= 250
+ * for the MFE, <= 120 for the partition function), else — also for a bracket pair of non-complementary bases — on the general
+ * int32 / FP64 kernels; same results either way.  Shuffles are folded unconstrained, as upstream. */
 #define SF_FOLD_NO_PF 1u
 #define SF_FOLD_NO_MFE 2u
 int sf_fold_constrained(const uint8_t *seqs, int n, int W, const char *cons, const int32_t *sc_stack_dcal,

@@ -62,6 +62,8 @@ def relaunch_under_torchrun(args):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__),
            "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup)]
     cmd += ["--config", args.config]
+    if args.no_live_counters:
+        cmd.append("--no-live-counters")
     if args.no_cpu_baseline:
         cmd.append("--no-cpu-baseline")
     proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
@@ -163,6 +165,45 @@ def _noop(x):
     return x
 
 
+def live_counters_per_fold(W, groups, n_folds=131072, timeout_s=150):
+    """Hardware counters of the dominant kernel per fold, measured NOW: one `rocprofv3 --pmc <group>` pass per group
+    (separate runs, as MI355X_MICROARCH.md prescribes) of tools/gpu_mfe_only.py as CHILD processes (this process keeps the
+    GPU; it is idle meanwhile).  -> ({counter: value per fold}, None) or (None, why not)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    tool = os.path.join(ROOT, "tools", "gpu_mfe_only.py")
+    vals = {}
+    tmp = tempfile.mkdtemp(prefix="sf_pmc_", dir="/tmp")
+    try:
+        for k, group in enumerate(groups):
+            out = os.path.join(tmp, "g%d" % k)
+            try:
+                p = subprocess.run([exe, "--pmc"] + group.split() + ["--kernel-trace", "--output-format", "csv", "-d", out, "--",
+                                    sys.executable, tool, str(n_folds), str(W)], cwd="/tmp",
+                                   env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
+                                   text=True, timeout=timeout_s)
+            except Exception as e:
+                return None, "rocprofv3 --pmc %s: %r" % (group, e)
+            got = {}
+            for f in glob.glob(os.path.join(out, "*", "*counter_collection.csv")):
+                for row in csv.DictReader(open(f)):
+                    # the timed launch of gpu_mfe_only.py is the one with a full persistent grid (its warm-up folds 1024 rows)
+                    if "sf_mfe_fast_kernel" in row["Kernel_Name"] and int(row["Grid_Size"]) >= 256 * 256:
+                        got[row["Counter_Name"]] = got.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+            missing = [c for c in group.split() if got.get(c, 0.0) <= 0.0]
+            if missing:
+                return None, "rocprofv3 --pmc %s gave no rows for %s (rc %d: %s)" % (group, missing, p.returncode, p.stderr[-200:])
+            vals.update(got)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return {k: v / n_folds for k, v in vals.items()}, None
+
+
 def reference_python_overhead(seq, W, r, windows=6):
     """What the reference adds per window on top of its ViennaRNA calls (ScanFold-Scan.py:73-77,256,269-274): r pure
     Python dinucleotide shuffles in the parent (scanfold_amd.functions.dinuclShuffle is the reference's function draw
@@ -220,6 +261,9 @@ def main():
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-counters", action="store_true",
+                    help="take roofline.traffic from the committed profiles/ file instead of two live rocprofv3 --pmc child "
+                         "runs (use when bench.py itself runs under rocprofv3)")
     ap.add_argument("--config", choices=sorted(WORKLOADS), default="cfg3",
                     help="cfg3 (default, the metric's own configuration) or cfg5 (W=200, r=1000, partition function)")
     args = ap.parse_args()
@@ -323,6 +367,29 @@ def main():
                     break
                 except Exception:
                     pass
+        traffic_src = counters_src and (counters_src + " (rocprofv3 --pmc passes of an earlier run, committed)")
+        secondary_src = counters_src and (counters_src + " (SQ counter passes of an earlier run, committed)")
+        if world == 1 and not args.no_live_counters:
+            nf = 131072 if W <= 128 else 65536
+            live, why = live_counters_per_fold(W, ["FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE",
+                                                   "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU"], nf)
+            if live is not None:
+                how = ("live: rocprofv3 --pmc child runs of tools/gpu_mfe_only.py %d %d after the timed region, one counter group "
+                       "per run" % (nf, W))
+                # gfx950 reports half of a read: bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB; L2 <-> fabric, Infinity-Cache hits included
+                traffic = (2.0 * live["FETCH_SIZE"] + live["WRITE_SIZE"]) * 1024.0 * folds_per_launch
+                traffic_src = how + "; (2 x FETCH_SIZE + WRITE_SIZE) KB per fold x the folds of one launch"
+                wc = live["SQ_WAVE_CYCLES"]
+                secondary = {"valu_busy": 4 * live["SQ_ACTIVE_INST_VALU"] / wc,
+                             "lanes_active_of_64": live["SQ_THREAD_CYCLES_VALU"] / max(live["SQ_ACTIVE_INST_VALU"], 1.0),
+                             "lds_busy": 4 * live["SQ_LDS_IDX_ACTIVE"] / wc, "waves_parked": live["SQ_WAIT_ANY"] / wc,
+                             "valu_insts_per_fold": live["SQ_INSTS_VALU"], "lds_insts_per_fold": live["SQ_INSTS_LDS"],
+                             "salu_insts_per_fold": live["SQ_INSTS_SALU"],
+                             "definition": "SQ counters of the MFE kernel per fold on random %d-mers; a SIMD hosts four of its "
+                                           "waves: busy = 4 x unit-active quad-cycles / wave quad-cycles of a fold" % W}
+                secondary_src = how
+            else:
+                traffic_src = (traffic_src or "none") + "; live measurement failed: " + why
         checked, bad = verify_sample(seq, W, step, r, kind, wl["shuffle_seed"], lo, n_loc, en, db, cen, div, wl["verify"])
         algorithmic_bytes = folds_per_launch * bytes_per_fold
         out = {
@@ -338,8 +405,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": algorithmic_bytes,
                          "traffic_over_algorithmic": (traffic / algorithmic_bytes) if traffic and algorithmic_bytes else None,
-                         "traffic_source": counters_src and (counters_src + " (rocprofv3 --pmc passes of this command, "
-                                                             "separate runs; not collected inside this run)"),
+                         "traffic_source": traffic_src,
+                         "secondary_source": secondary_src,
                          "kernel": "sf_mfe_fast_kernel", "avg_launch_ms": avg_ms, "launches": launches,
                          "folds_per_launch": folds_per_launch, "algorithmic_bytes_per_fold": bytes_per_fold,
                          "note": "integer min-plus DP on LDS-resident tables: LDS/VALU-bound by construction "

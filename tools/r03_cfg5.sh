@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT; V=${V:-r03_cfg5}; O=$R/gpurun_out/$V
 cd /tmp && export TMPDIR=/tmp
 mkdir -p $O
 python3 $R/bench.py --config cfg5 > $O/cfg5_bench.json 2> $O/cfg5_bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --config cfg5 --no-cpu-baseline > $O/cfg5_bench_under_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --config cfg5 --no-cpu-baseline --no-live-counters > $O/cfg5_bench_under_rocprof.json 2>/dev/null
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -- python3 $R/tools/gpu_mfe_only.py 262144 200 > /dev/null 2>&1
 done

@@ -165,7 +165,7 @@ def _noop(x):
     return x
 
 
-def live_counters_per_fold(W, groups, n_folds=131072, timeout_s=150):
+def live_counters_per_fold(W, groups, n_folds=131072, timeout_s=60):
     """Hardware counters of the dominant kernel per fold, measured NOW: one `rocprofv3 --pmc <group>` pass per group
     (separate runs, as MI355X_MICROARCH.md prescribes) of tools/gpu_mfe_only.py as CHILD processes (this process keeps the
     GPU; it is idle meanwhile).  -> ({counter: value per fold}, None) or (None, why not)."""

@@ -254,7 +254,11 @@ struct SfFastCtx {
 // small enough (13.6 kB per workgroup at W=120) that the whole grid's scratch stays in L2 between the fill and
 // the exterior pass, which reads it row by row
 #define SF_CGIDX(i, j) (((i)-1) * (W - 3) - (((i)-1) * (i)) / 2 + ((j) - (i)-4))
-#define SF_CG_ENTRIES(W) (((((W)-4) * ((W)-3)) / 2 + 8 + 1) & ~1)  // even: a workgroup's slice stays 4-byte aligned
+// (even: a workgroup's slice stays 4-byte aligned.  The slice stride decides how the workgroups' tables fall on the L2's
+// channels and lines, and with it how often a partially written line is evicted before its row is complete: at W = 120,
+// L2 -> fabric writes per fold 4.1-4.3 kB at 6794 entries, 3.3 kB at 6796 or 6812, 4.0 at 6820, 5.7-7.7 at 6832..6896, and
+// 9-16 kB whenever the stride is a whole number of 128-byte lines (6848, 6912, 6976) — profiles/r03/mfe_scratch_stride.txt)
+#define SF_CG_ENTRIES(W) (((((W)-4) * ((W)-3)) / 2 + 8 + 3) & ~1)
 
 // Size-dependent terms (loop initiation, asymmetry) are the same for every lane: they are read from small LDS
 // tables with a wave-uniform address (a broadcast read).  (Keeping them spread over the lanes of a VGPR and

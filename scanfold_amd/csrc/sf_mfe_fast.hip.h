@@ -34,7 +34,9 @@
 // previous cell.  Bulges (2 per size), 1 x n loops (2 per size) and the 9 special candidates are direct.
 // Size-dependent terms are wave-uniform reads of small LDS tables (per-wave guarded copies on short diagonals).
 //
-// c + ExtLoop is streamed to a device scratch table (int16, L2-resident) for the exterior-loop sweep at the end.
+// c + ExtLoop is streamed to a device scratch table (int16, L2-resident) for the exterior-loop sweep, which trails the fill
+// inside the same fold (SfTrail: the 3' -> 5' recurrence on the rows that are already complete; folds whose structure is
+// wanted keep the 5' -> 3' sweep at their end, whose f5[] the traceback reads).
 //
 // int16 is exact while |energy| < 12000 dcal/mol; a fold that leaves that range (a >120 kcal/mol helix) is
 // appended to an overflow list and redone by the int32 kernel (sf_mfe_full.hip.h), so results never depend

@@ -151,3 +151,32 @@ def test_cli_gpus_2_over_gloo_writes_the_single_process_tsv(tmp_path):
         b = _run_cli(base + ["--gpus", "2", "-o", str(two)], env)
         assert b.returncode == 0, b.stderr[-2000:]
         assert one.read_bytes() == two.read_bytes() and one.read_text().count("\n") == 1 + 9, extra
+
+
+ROWS_WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, %(root)r)
+    import torch.distributed as dist
+    from scanfold_amd import dist as sdist
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    n_win, W = int(os.environ["N_WIN"]), 20
+    allrows = ["%%d\\t%%d\\t37\\t-%%d.5\\t%%s\\n" %% (k + 1, k + W, k, "ACGU" * 5) for k in range(n_win)]
+    lo, hi = sdist.shard_range(n_win, rank, world)
+    got = sdist.gather_rows(allrows[lo:hi], n_win, rank, world, W, device=None, want=(rank == 0))
+    ok = (got == allrows) if rank == 0 else (got is None)
+    print("RANK%%d_ROWS_OK=%%s" %% (rank, bool(ok)))
+    dist.destroy_process_group()
+""")
+
+
+@pytest.mark.parametrize("nproc,n_win", [(2, 7), (2, 1), (4, 2)])
+def test_row_gather_over_gloo_ragged_and_empty_shards(tmp_path, nproc, n_win):
+    """dist.gather_rows (the command line's one collective): ragged last shard, ranks with no window at all; only the
+    writing rank unpacks."""
+    script = tmp_path / "rows_worker.py"
+    script.write_text(ROWS_WORKER % {"root": ROOT})
+    out = run_ranks(script, nproc, {"N_WIN": str(n_win)})
+    assert out.returncode == 0, out.stderr[-2000:]
+    for rank in range(nproc):
+        assert "RANK%d_ROWS_OK=True" % rank in out.stdout, out.stdout + out.stderr[-1000:]

@@ -32,7 +32,8 @@
 // H[i,j,u] = min(H[i+1,j-1,u-2], the two edge candidates u1=2 and u2=2): 2 LDS reads per u instead of u-3,
 // exact (same minimum over the same set).  H lives in registers because (i+1,j-1) is the same thread's
 // previous cell.  Bulges (2 per size), 1 x n loops (2 per size) and the 9 special candidates are direct.
-// Size-dependent terms are wave-uniform reads of small LDS tables (per-wave guarded copies on short diagonals).
+// Size-dependent terms are wave-uniform reads of small tables in device memory (scalar loads; guarded copies for the short
+// diagonals, SfFastParams::uniG).
 //
 // c + ExtLoop is streamed to a device scratch table (int16, L2-resident) for the exterior-loop sweep, which trails the fill
 // inside the same fold (SfTrail: the 3' -> 5' recurrence on the rows that are already complete; folds whose structure is
@@ -51,7 +52,7 @@
 #define SF_FAST_TINY_D0 12
 // even diagonals below this one skip whole batches of loop sizes above the limit (CH); from here to 36 the skipped
 // work is small and the unbroken straight-line code is faster (measured: 20 / 24 / 28 / 36 -> 87.5 / 87.1 / 87.0 / 87.9 ms)
-#define SF_FAST_CHUNK_D0 28
+#define SF_FAST_CHUNK_D0 36
 #define SF_FAST_SPLIT 1  // long diagonals: the idle second wave of a group takes part of the cell's work
 // split steps at W <= 128: 1 = ONE helper wave serves both diagonals of a step, on a compacted list of the cells that
 // can pair (3 of 8): the special / bulge / 1xn block runs once per step instead of twice
@@ -98,6 +99,12 @@ struct SfFastParams {
   uint8_t rpair[64];   // rtype(pair[a][b])
   int16_t stackT[64], mm23in[200];
   int16_t int11T[8 * 8 * 25], int21a[8 * 8 * 125], int21b[8 * 8 * 125], int22T[8 * 8 * 625];
+  // the size tables in the layout of their LDS copy (NIN[32] | IL[32] | (BUL[u], L1N[u-1]) pairs): read with wave-uniform
+  // addresses from HERE — scalar loads, off the LDS pipe — by the code that needs no guarded copy (diagonals >= 36)
+  int16_t uni[128];
+  // ... and its guarded copies for the short diagonals: uniG[um] = uni with the entries of loop sizes above um at 32767
+  // (what the kernels used to build per wave and step in LDS); um = d - 6 = 0..30
+  int16_t uniG[31][128];
 };
 
 static inline void sf_fast_build_params(const SfDevParams &D, SfFastParams &F) {
@@ -167,18 +174,29 @@ static inline void sf_fast_build_params(const SfDevParams &D, SfFastParams &F) {
   for (int t = 0; t < 8; t++)
     for (int a = 0; a < 5; a++)
       for (int b = 0; b < 5; b++) F.mm23in[t * 25 + a * 5 + b] = off16(P.mismatch23I[t][a][b], tau(t));
+  for (int x = 0; x < 32; x++) {
+    F.uni[x] = (int16_t)(F.NIN[x] < 32000 ? F.NIN[x] : 32000);
+    F.uni[32 + x] = (int16_t)(F.IL[x] < 32000 ? F.IL[x] : 32000);
+    F.uni[64 + 2 * x] = (int16_t)(F.BUL[x] < 32000 ? F.BUL[x] : 32000);
+    F.uni[64 + 2 * x + 1] = x >= 4 ? (int16_t)(F.L1N[x - 1] < 32000 ? F.L1N[x - 1] : 32000) : (int16_t)32767;
+  }
+  for (int um = 0; um <= 30; um++)
+    for (int e = 0; e < 128; e++) {
+      const int u = e < 32 ? e + 4 : (e < 64 ? e - 32 : (e - 64) >> 1);  // NIN[u-4], IL[u], (BUL[u], L1N[u-1])
+      F.uniG[um][e] = u <= um ? F.uni[e] : (int16_t)32767;
+    }
 }
 
 // LDS carve (bytes); every piece a multiple of 4
 struct SfFastLayout {
   int tri;  // int16 entries of the fML triangle (diagonals >= 4)
   int off_ci, off_c1n, off_cb, off_dml, off_list, off_next, off_tab, off_red, off_flag, off_S;
-  int off_guard;  // per-wave copies of the size tables for the short diagonals (sf_fast_guard_tables)
   int off_hc;     // (hc layouts) constraint characters | partners | enclosing pairs | int16 pseudo-energies
   int total;
 };
 // int16 entries: mismatch23 rows 0..6 (175), five more mismatch tables rows 1..6 (150 each), stack (64; holds
-// stackT), d5, d3 (40 each), pair (64 bytes), one pad, four size tables (32 each), reversed pair types (64 bytes),
+// stackT), d5, d3 (40 each), pair (64 bytes), one pad, the size tables (4 x 32: the size-tested code of the first four steps
+// reads them here), reversed pair types (64 bytes),
 // mismatch23 minus the terminal penalty of its type, rows 0..6 (175), one pad
 #define SF_FAST_TAB_OLD (175 + 5 * 150 + 64 + 40 + 40 + 32 + 1 + 4 * 32)
 #define SF_FAST_TAB_BYTES ((SF_FAST_TAB_OLD + 32 + 175 + 1) * 2)
@@ -216,12 +234,6 @@ static inline __host__ __device__ SfFastLayout sf_fast_layout(int W, bool hc = f
   L.off_S = o; o += (W + 2 + 3) & ~3;
   L.off_hc = o;
   if (hc) o += ((5 * (W + 2) + 3) & ~3);
-  // 256 bytes per wave, needed while d < 36 only: from W = 96 on they lie in the end of the fML triangle, whose
-  // last 45 diagonals (>= 2 kB from W = 96 on, first written at d = W-45 >= 51) are still unused by then
-  const int guard_bytes = (W <= 128 ? 4 : 8) * 256;
-  if (W > 128) L.off_guard = 32 * (W - 3) * 2;  // FOLD: rows 32.. hold diagonals 36..W-33 only (first written at d = 36)
-  else if (W >= 96) L.off_guard = tri * 2 - guard_bytes;
-  else { L.off_guard = o; o += guard_bytes; }
   L.total = o;
   return L;
 }
@@ -246,9 +258,9 @@ struct SfFastCtx {
   int maxd;     // largest allowed j - i of a base pair (max_bp_span - 1)
   SfHc8 hc;     // the fold's hard constraint (hc.c null: none)
   const int16_t *sc;  // its Deigan pseudo-energies, 1-based, or null
-  const int16_t *uNIN, *uIL, *uL1N, *uBUL;  // size-dependent terms, LDS copies (uniform reads)
+  const int16_t *uNIN;  // LDS copy of SfFastParams::uni (the size-tested code of diagonals < 12 reads it)
   int16_t *BN;  // sf_mfe_fast_kernel: the bulge and 1xn rolling tables interleaved, entry x = (CB[x], C1N[x]) in one
-                // 32-bit word (CB / C1N above stay null there); uNIN = [NIN 32][IL 32][(BUL[u], L1N[u-1]) 32 pairs]
+                // 32-bit word (CB / C1N above stay null there)
 };
 
 #define SF_TIDX(t, a, b) ((t)*25 + (a)*5 + (b))
@@ -361,11 +373,18 @@ template <bool G, int WT, int SEC, bool CH = false, bool FOLD = false, int UCAP 
 __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, const int i, const bool valid,
                                              const int slot2, const int slotd, uint32_t (&HP)[14], int &ovf,
                                              const bool final_fml, const int fnb, int &fpart, int &dec, int &eh, int &e0,
-                                             const int16_t *uni, int &dprev, SfPub &pub, const int dml_lo = SFD_TURN + 1,
+                                             int &dprev, SfPub &pub, const int dml_lo = SFD_TURN + 1,
                                              const int dml_hi = 1 << 20) {
-  // size tables [4][32]: asymmetry, loop initiation, 1xn, bulge (the kernel passes guarded copies on short diagonals)
+  // size tables: NIN[32] asymmetry | IL[32] loop initiation | 32 pairs (bulge[u], 1xn term of total size u — 32767 for u < 4)
   // third table: 32-bit pairs (bulge[u], 1xn term of total size u — 32767 for u < 4, where no 1xn loop exists)
-  const int16_t *const uNIN = uni, *const uIL = uni + 32, *const uBN = uni + 64;
+  // The size tables are the same for every lane: they are read from DEVICE memory with wave-uniform addresses — scalar loads
+  // through the scalar cache, off the LDS pipe (round 3: their LDS copy cost 56 broadcast reads per cell pass, a quarter of a
+  // pass's LDS instructions; +1.5 % at W = 120).  CH (12 <= d < 36): the guarded copy for this diagonal's largest loop size —
+  // sizes above it cost 32767 (round 2 built that copy per wave and step in LDS).
+  // (G, the first four steps: every use sits behind its own size test — a scalar load there would be waited for on the
+  // spot; that code keeps reading an LDS copy: measured 1 % faster at W = 200.)
+  const int16_t *const ubase = G ? X.uNIN : (CH ? X.F->uniG[sfd_max(sfd_min(d - 2 - (SFD_TURN + 1), 30), 0)] : X.F->uni);
+  const int16_t *const uNIN = ubase, *const uIL = ubase + 32, *const uBN = ubase + 64;
 // Word x of a row holds (CB[x], C1N[x+1]) — the two left-edge candidates of a size, CB at column 1 and C1N at column
 // 2, are then ONE word.  (SHIFT = false: (CB[x], C1N[x]), the layout until late in round 2.)
   constexpr bool SHIFT = true;
@@ -1130,7 +1149,6 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
   X.tE = tab + 775 - 25; X.cg_ext = 1;
   X.tStack = tab + 925; X.tD5 = tab + 989; X.tD3 = tab + 1029;
   uint8_t *tPair = (uint8_t *)(tab + 1069);
-  int16_t *guard = (int16_t *)(smem + Lo.off_guard);
   X.tPair = tPair;
   uint8_t *tRPair = (uint8_t *)(tab + SF_FAST_TAB_OLD);
   int16_t *t23in = tab + SF_FAST_TAB_OLD + 32;
@@ -1164,12 +1182,8 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
 
   {
     int16_t *uni = tab + 1069 + 32 + 1;  // after the 64-byte pair table, at an even index (read as 32-bit pairs)
-    X.uNIN = uni; X.uIL = uni + 32; X.uL1N = nullptr; X.uBUL = nullptr;  // (uni + 64: the pair table, see SfFastCtx::BN)
-    for (int x = tid; x < 32; x += NT) {
-      uni[x] = (int16_t)sfd_min(F->NIN[x], 32000); uni[32 + x] = (int16_t)sfd_min(F->IL[x], 32000);
-      uni[64 + 2 * x] = (int16_t)sfd_min(F->BUL[x], 32000);                               // bulge[u], u = x
-      uni[64 + 2 * x + 1] = x >= 4 ? (int16_t)sfd_min(F->L1N[x - 1], 32000) : (int16_t)32767;  // 1xn of total size u
-    }
+    X.uNIN = uni;
+    for (int x = tid; x < 128; x += NT) uni[x] = F->uni[x];
   }
   // the rolling tables start out as "no structure": the guarded short-diagonal code reads rows no diagonal of the
   // first fold has written yet (later folds find the previous fold's energies there, which is as good)
@@ -1305,23 +1319,6 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
       int dec = SF_FAST_BIG, eh = SF_FAST_BIG, e0 = SF_FAST_BIG;
       SfPub pub;
       pub.a = pub.b = 0; pub.tau = 0;
-      // Short diagonals (d < 36): loop sizes above d-6 do not exist.  Instead of testing every size (a branch per
-      // size, nothing in flight across it), the cell runs the same straight-line code as on long diagonals with
-      // this wave's copy of the size tables in which those sizes cost 32767: their candidates (stale but
-      // energy-sized table entries) saturate / stay far above every real one.
-      const int16_t *uni = X.uNIN;
-      if (d0 >= SF_FAST_TINY_D0 && d0 < SFD_MAXLOOP + 6) {
-        int16_t *gt = guard + (tid >> 6) * 128;
-        const int um = d - 2 - (SFD_TURN + 1);
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-          const int e = (tid & 63) + 64 * h;
-          const int u = e < 32 ? e + 4 : (e < 64 ? e - 32 : (e - 64) >> 1);  // NIN[u-4], IL[u], (BUL[u], L1N[u-1])
-          gt[e] = u <= um ? X.uNIN[e] : (int16_t)32767;
-        }
-        SF_WAVE_SYNC();
-        uni = gt;
-      }
       // trailing sweep: the rows i >= W-d0+1 are complete (diagonals < d0 are); this step's rows are requested now, used
       // after the wave's own work
       int dc[DROWS][NQ];
@@ -1333,13 +1330,13 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
           if (k < sweep_rows) sf_trail_load<NQ>(X.cg, W, tid & 63, T.row - k, dc[k]);
       }
       if (__ballot(valid)) {
-        if (d0 < 8) sf_fast_cell<true, WT, SF_SEC_ALL, false, FOLD, 1>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev, pub);
-        else if (d0 < SF_FAST_TINY_D0) sf_fast_cell<true, WT, SF_SEC_ALL, false, FOLD, 5>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev, pub);
-        else if (d0 < SF_FAST_CHUNK_D0) sf_fast_cell<false, WT, SF_SEC_ALL, true, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev, pub);
-        else if (!split) sf_fast_cell<false, WT, SF_SEC_ALL, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev, pub);
+        if (d0 < 8) sf_fast_cell<true, WT, SF_SEC_ALL, false, FOLD, 1>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
+        else if (d0 < SF_FAST_TINY_D0) sf_fast_cell<true, WT, SF_SEC_ALL, false, FOLD, 5>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
+        else if (d0 < SF_FAST_CHUNK_D0) sf_fast_cell<false, WT, SF_SEC_ALL, true, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
+        else if (!split) sf_fast_cell<false, WT, SF_SEC_ALL, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
         else if (!helper) {
-          if (SHARE) sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_DML | SF_SEC_PRE, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev, pub, SFD_TURN + 1, dml_cut - 1);
-          else sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_DML | SF_SEC_PRE, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev, pub);
+          if (SHARE) sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_DML | SF_SEC_PRE, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub, SFD_TURN + 1, dml_cut - 1);
+          else sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_DML | SF_SEC_PRE, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
         } else if (MERGE) {
           // Merged helper (W <= 128).  ONE helper wave serves both diagonals of the step: it works on the list of the
           // cells of d0 and d0+1 that can pair (build_list above; 3 of 8 cells, so ordinary sequences fit wave 1's 64
@@ -1359,7 +1356,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
             const int sd1 = sd0 + 1 >= SF_FAST_NR ? 0 : sd0 + 1;
             SfFastCtx Xh = X;
             Xh.BN = X.BN + 2 * g * (W - 4);
-            sf_fast_cell<false, WT, SF_SEC_HELP, false, FOLD>(Xh, d0 + g, iC, vC, s2, sd0, H, ovf, false, fnb, fpart, dec, eh, e0, uni, dprev, pub);
+            sf_fast_cell<false, WT, SF_SEC_HELP, false, FOLD>(Xh, d0 + g, iC, vC, s2, sd0, H, ovf, false, fnb, fpart, dec, eh, e0, dprev, pub);
             if (vC) X.BN[2 * ((g ? sd1 : sd0) * (W - 4) + iC - 1)] = (int16_t)sfd_min(eh, 32000);
           }
         } else {
@@ -1367,13 +1364,13 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
           // step, and rewritten by nobody but the cell's own lane): eh in the CB half of its word, its part of the
           // multiloop split in its CI entry
           if (SHARE) {
-            sf_fast_cell<false, WT, SF_SEC_HELP | SF_SEC_DML, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev, pub, dml_cut);
+            sf_fast_cell<false, WT, SF_SEC_HELP | SF_SEC_DML, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub, dml_cut);
             if (valid) {
               X.BN[2 * (slotd * (W - 4) + i - 1)] = (int16_t)sfd_min(eh, 32000);
               X.CI[slotd * (W - 4) + i - 1] = (int16_t)sfd_min(dec, 32000);
             }
           } else {
-            sf_fast_cell<false, WT, SF_SEC_HELP, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev, pub);
+            sf_fast_cell<false, WT, SF_SEC_HELP, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
             if (valid) X.BN[2 * (slotd * (W - 4) + i - 1)] = (int16_t)sfd_min(eh, 32000);
           }
         }
@@ -1388,7 +1385,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
             eh = X.BN[2 * (slotd * (W - 4) + i - 1)];
             if (SHARE) dec = sfd_min(dec, (int)X.CI[slotd * (W - 4) + i - 1]);
           }
-          sf_fast_cell<false, WT, SF_SEC_FIN | SF_SEC_POST, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, uni, dprev, pub);
+          sf_fast_cell<false, WT, SF_SEC_FIN | SF_SEC_POST, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
         }
       }
       __syncthreads();

@@ -61,6 +61,14 @@ int sf_device_name(char *buf, size_t n); /* e.g. "AMD Instinct MI355X (gfx950), 
  * temperature_c must equal blob->temperature (free energies are not rescaled on the device yet). */
 int sf_params_load(const void *blob, size_t nbytes, double temperature_c);
 
+/* md.temperature = T with T != 37 (ScanFold-Scan.py:70-71; ScanFoldFunctions.py:776-777): `blob` holds the free
+ * energies rescaled to T and truncated to integers (what the MFE recursions use); blob_37c and blob_enthalpy are the
+ * same struct holding the 37 C free energies and the enthalpies it was rescaled from.  The Boltzmann weights of the
+ * partition function are then built from the un-truncated dG(T) = dH - (dH - dG37) (T + 273.15) / 310.15, as ViennaRNA's
+ * get_boltzmann_factors does [EXT].  Both NULL: exactly sf_params_load. */
+int sf_params_load_rescaled(const void *blob, size_t nbytes, double temperature_c, const void *blob_37c,
+                            const void *blob_enthalpy);
+
 /* energies(seq_list) / rna_folder(frag): MFE of n sequences of W nt, no structure
  * (ScanFold-Scan.py:244-246,253-262; ScanFoldFunctions.py:774-789,805-814).  mfe_dcal_out[n]. */
 int sf_mfe_batch(const uint8_t *seqs, int n, int W, int32_t *mfe_dcal_out);

@@ -26,6 +26,7 @@ def lib():
             build()
         L = ctypes.CDLL(_LIB)
         L.sfo_set_params.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+        L.sfo_set_params_exact.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_char_p]
         L.sfo_mfe.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_char_p]
         L.sfo_mfe_batch.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
         L.sfo_eval.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
@@ -48,7 +49,8 @@ def lib():
 def set_params(paramset):
     blob = paramset.blob()
     assert len(blob) == lib().sfo_params_size(), (len(blob), lib().sfo_params_size())
-    rc = lib().sfo_set_params(blob, len(blob))
+    b37, bdh = paramset.rescale_blobs()
+    rc = lib().sfo_set_params_exact(blob, len(blob), b37, bdh)
     if rc:
         raise RuntimeError("sfo_set_params rc=%d" % rc)
 

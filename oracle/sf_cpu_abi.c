@@ -21,6 +21,7 @@
 
 /* the restatement's entry points (sf_oracle.c, sf_cpu_twin.c, sf_shuffle_oracle.c) */
 int sfo_set_params(const void *blob, size_t n);
+int sfo_set_params_exact(const void *blob, size_t n, const void *blob37, const void *blob_dH);
 int sfo_set_constraint(const char *cons, const int *sc_stack_dcal);
 int sfo_set_max_bp_span(int span);
 int sfo_mfe(const char *seq, int n, int *mfe_dcal, char *structure);
@@ -72,12 +73,17 @@ int sf_device_name(char *buf, size_t n) {
   return SF_OK;
 }
 int sf_params_load(const void *blob, size_t nbytes, double temperature_c) {
+  return sf_params_load_rescaled(blob, nbytes, temperature_c, NULL, NULL);
+}
+int sf_params_load_rescaled(const void *blob, size_t nbytes, double temperature_c, const void *blob_37c,
+                            const void *blob_enthalpy) {
   if (!g_init) return SF_ERR_NOT_INIT;
+  if ((blob_37c == NULL) != (blob_enthalpy == NULL)) return SF_ERR_BAD_ARG;
   if (!blob || nbytes != sizeof(sf_params_blob)) return SF_ERR_BAD_PARAMS;
   const sf_params_blob *P = (const sf_params_blob *)blob;
   if (P->magic != SF_PARAMS_MAGIC || P->version != SF_PARAMS_VERSION) return SF_ERR_BAD_PARAMS;
   if (fabs(P->temperature - temperature_c) > 1e-9) return SF_ERR_TEMPERATURE;
-  if (sfo_set_params(blob, nbytes)) return SF_ERR_BAD_PARAMS;
+  if (sfo_set_params_exact(blob, nbytes, blob_37c, blob_enthalpy)) return SF_ERR_BAD_PARAMS;
   g_have_params = 1;
   return SF_OK;
 }

@@ -73,60 +73,96 @@ static double smooth(double x) {
   return SCALE * 0.38490018 * s * s;
 }
 
+/* Free energy behind one Boltzmann weight.  ViennaRNA's get_boltzmann_factors [EXT] rescales each entry from the 37 C
+ * value and its enthalpy in double, dG(T) = dH - (dH - dG37) * (T + K0) / (37 + K0), and does NOT truncate it to an
+ * integer the way the MFE tables are (md.pf_smooth, the default).  When the caller handed over the 37 C and enthalpy
+ * records (sfo_set_params_exact) the weight of field `*ref` of P is taken from the same field of those; otherwise from
+ * the integer in P.  At 37 C both are the same number. */
+static const sf_params_blob *P37x = NULL, *PdHx = NULL;
+static double exact_energy(const int32_t *ref) {
+  if (!P37x) return (double)*ref;
+  size_t off = (size_t)((const char *)ref - (const char *)&P);
+  int32_t g = *(const int32_t *)((const char *)P37x + off), h = *(const int32_t *)((const char *)PdHx + off);
+  if (g >= INF || g <= -INF) return (double)*ref;
+  double tempf = (P.temperature + K0) / (37.0 + K0);
+  return (double)h - ((double)h - (double)g) * tempf;
+}
+
 static void build_exp_params(void) {
   if (!XP) XP = (exp_params *)malloc(sizeof(exp_params));
   exp_params *x = XP;
   x->kT = (P.temperature + K0) * GASCONST;
   const double kT = x->kT;
+#define EX(f) exact_energy(&(f))
 #define BW(e) exp(-(double)(e)*10.0 / kT)
 #define BWS(e) exp(smooth(-(double)(e)) * 10.0 / kT)
   for (int a = 0; a < 8; a++)
-    for (int b = 0; b < 8; b++) x->stack[a][b] = BW(P.stack[a][b]);
+    for (int b = 0; b < 8; b++) x->stack[a][b] = BW(EX(P.stack[a][b]));
   for (int i = 0; i <= 30; i++) {
-    x->hairpin[i] = BW(P.hairpin[i]);
-    x->bulge[i] = BW(P.bulge[i]);
-    x->internal_loop[i] = BW(P.internal_loop[i]);
-    x->ninio[i] = BW(MIN2(P.max_ninio, i * P.ninio));
+    x->hairpin[i] = BW(EX(P.hairpin[i]));
+    x->bulge[i] = BW(EX(P.bulge[i]));
+    x->internal_loop[i] = BW(EX(P.internal_loop[i]));
+    x->ninio[i] = BW(MIN2((double)P.max_ninio, i * EX(P.ninio)));
   }
   for (int t = 0; t < 8; t++)
     for (int a = 0; a < 5; a++) {
-      x->dangle5[t][a] = BWS(P.dangle5[t][a]);
-      x->dangle3[t][a] = BWS(P.dangle3[t][a]);
+      x->dangle5[t][a] = BWS(EX(P.dangle5[t][a]));
+      x->dangle3[t][a] = BWS(EX(P.dangle3[t][a]));
       for (int b = 0; b < 5; b++) {
-        x->mismatchI[t][a][b] = BW(P.mismatchI[t][a][b]);
-        x->mismatchH[t][a][b] = BW(P.mismatchH[t][a][b]);
-        x->mismatch1nI[t][a][b] = BW(P.mismatch1nI[t][a][b]);
-        x->mismatch23I[t][a][b] = BW(P.mismatch23I[t][a][b]);
-        x->mismatchM[t][a][b] = BWS(P.mismatchM[t][a][b]);
-        x->mismatchExt[t][a][b] = BWS(P.mismatchExt[t][a][b]);
+        x->mismatchI[t][a][b] = BW(EX(P.mismatchI[t][a][b]));
+        x->mismatchH[t][a][b] = BW(EX(P.mismatchH[t][a][b]));
+        x->mismatch1nI[t][a][b] = BW(EX(P.mismatch1nI[t][a][b]));
+        x->mismatch23I[t][a][b] = BW(EX(P.mismatch23I[t][a][b]));
+        x->mismatchM[t][a][b] = BWS(EX(P.mismatchM[t][a][b]));
+        x->mismatchExt[t][a][b] = BWS(EX(P.mismatchExt[t][a][b]));
       }
     }
   for (int a = 0; a < 8; a++)
     for (int b = 0; b < 8; b++)
       for (int c = 0; c < 5; c++)
         for (int d = 0; d < 5; d++) {
-          x->int11[a][b][c][d] = BW(P.int11[a][b][c][d]);
+          x->int11[a][b][c][d] = BW(EX(P.int11[a][b][c][d]));
           for (int e = 0; e < 5; e++) {
-            x->int21[a][b][c][d][e] = BW(P.int21[a][b][c][d][e]);
-            for (int f = 0; f < 5; f++) x->int22[a][b][c][d][e][f] = BW(P.int22[a][b][c][d][e][f]);
+            x->int21[a][b][c][d][e] = BW(EX(P.int21[a][b][c][d][e]));
+            for (int f = 0; f < 5; f++) x->int22[a][b][c][d][e][f] = BW(EX(P.int22[a][b][c][d][e][f]));
           }
         }
-  x->MLbase = BW(P.MLbase);
-  x->MLclosing = BW(P.MLclosing);
-  for (int t = 0; t < 8; t++) x->MLintern[t] = BW(P.MLintern[t]);
-  x->TermAU = BW(P.TerminalAU);
+  x->MLbase = BW(EX(P.MLbase));
+  x->MLclosing = BW(EX(P.MLclosing));
+  for (int t = 0; t < 8; t++) x->MLintern[t] = BW(EX(P.MLintern[t]));
+  x->TermAU = BW(EX(P.TerminalAU));
   for (int k = 0; k < SF_MAX_SPECIAL; k++) {
-    x->tetra[k] = BW(P.tetra_E[k]);
-    x->tri[k] = BW(P.tri_E[k]);
-    x->hexa[k] = BW(P.hexa_E[k]);
+    x->tetra[k] = BW(EX(P.tetra_E[k]));
+    x->tri[k] = BW(EX(P.tri_E[k]));
+    x->hexa[k] = BW(EX(P.hexa_E[k]));
   }
 #undef BW
 #undef BWS
+#undef EX
 }
 
 int sfo_params_size(void) { return (int)sizeof(sf_params_blob); }
 
+static int set_params_impl(const void *blob, size_t n);
 int sfo_set_params(const void *blob, size_t n) {
+  P37x = PdHx = NULL;
+  return set_params_impl(blob, n);
+}
+/* As sfo_set_params, with the records the set was rescaled from: the free energies at 37 C and the enthalpies (same
+ * struct).  The MFE model still uses the truncated integers of `blob`; the Boltzmann weights use the exact doubles. */
+int sfo_set_params_exact(const void *blob, size_t n, const void *blob37, const void *blob_dH) {
+  static sf_params_blob A, B;
+  if (n != sizeof(sf_params_blob)) return -1;
+  if (!blob37 || !blob_dH) return sfo_set_params(blob, n);
+  memcpy(&A, blob37, sizeof A);
+  memcpy(&B, blob_dH, sizeof B);
+  P37x = &A;
+  PdHx = &B;
+  int rc = set_params_impl(blob, n);
+  P37x = PdHx = NULL;
+  return rc;
+}
+static int set_params_impl(const void *blob, size_t n) {
   if (n != sizeof(sf_params_blob)) return -1;
   memcpy(&P, blob, sizeof(P));
   if (P.magic != SF_PARAMS_MAGIC || P.version != SF_PARAMS_VERSION) return -2;

@@ -27,6 +27,8 @@ _EXPORTS = {
     "sf_shutdown": (ctypes.c_int, []),
     "sf_device_name": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_size_t]),
     "sf_params_load": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_double]),
+    "sf_params_load_rescaled": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_double, ctypes.c_char_p,
+                                               ctypes.c_char_p]),
     "sf_mfe_batch": (ctypes.c_int, [_c_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "sf_mfe_batch_dev": (ctypes.c_int, [_c_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "sf_mfe_trace_batch": (ctypes.c_int, [_c_u8p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
@@ -144,10 +146,14 @@ class Engine:
         set's own rescales it first (ParamSet.at_temperature: needs the enthalpy tables of a real .par file)."""
         if temperature is not None and float(temperature) != paramset.temperature:
             paramset = paramset.at_temperature(temperature)
-        blob = paramset.blob()
-        self._check(self.lib.sf_params_load(blob, len(blob), paramset.temperature))
+        self._load(paramset)
         self.params = paramset
         self._by_temp = {paramset.temperature: paramset}
+
+    def _load(self, p):
+        blob = p.blob()
+        b37, bdh = p.rescale_blobs()
+        self._check(self.lib.sf_params_load_rescaled(blob, len(blob), p.temperature, b37, bdh))
 
     def set_temperature(self, temperature):
         """md.temperature = T (ScanFold-Scan.py:70-71; ScanFoldFunctions.py:776-777): switch the resident model to the
@@ -160,8 +166,7 @@ class Engine:
         if t not in cache:
             cache[t] = self.params.at_temperature(t)
         p = cache[t]
-        blob = p.blob()
-        self._check(self.lib.sf_params_load(blob, len(blob), p.temperature))
+        self._load(p)
         self.params = p
 
     def shutdown(self):

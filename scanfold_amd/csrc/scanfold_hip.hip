@@ -113,7 +113,11 @@ uint32_t pack_key(const char *s, int len) {
   return k;
 }
 
-void build_dev_params(const sf_params_blob &P, SfDevParams &D, SfDevParamsPF &X) {
+// P37 / PdH (both or neither): the 37 C free energies and the enthalpies `P` was rescaled from.  With them every Boltzmann
+// weight comes from the un-truncated double dG(T) = dH - (dH - dG37) (T + K0) / (37 + K0), as ViennaRNA's
+// get_boltzmann_factors computes it (md.pf_smooth, its default) [EXT]; the MFE tables stay the truncated integers of P.
+void build_dev_params(const sf_params_blob &P, SfDevParams &D, SfDevParamsPF &X, const sf_params_blob *P37 = nullptr,
+                      const sf_params_blob *PdH = nullptr) {
   memset(&D, 0, sizeof D);
   D.P = P;
   for (int s = 0; s <= SF_MAX_W + 1; s++)
@@ -128,48 +132,56 @@ void build_dev_params(const sf_params_blob &P, SfDevParams &D, SfDevParamsPF &X)
   memset(&X, 0, sizeof X);
   const double kT = (P.temperature + 273.15) * 1.98717;
   X.kT = kT;
+  const double tempf = (P.temperature + 273.15) / (37.0 + 273.15);
+  auto ex = [&](const int32_t &ref) -> double {  // the energy behind field `ref` of P
+    if (!P37 || !PdH) return (double)ref;
+    const size_t off = (size_t)((const char *)&ref - (const char *)&P);
+    const int32_t g37 = *(const int32_t *)((const char *)P37 + off), dh = *(const int32_t *)((const char *)PdH + off);
+    if (g37 >= SF_INF || g37 <= -SF_INF) return (double)ref;
+    return (double)dh - ((double)dh - (double)g37) * tempf;
+  };
   auto bw = [kT](double e) { return exp(-e * 10.0 / kT); };
   auto bws = [kT](double e) { return exp(smooth_term(-e) * 10.0 / kT); };
   for (int a = 0; a < 8; a++)
-    for (int b = 0; b < 8; b++) X.stack[a][b] = bw(P.stack[a][b]);
+    for (int b = 0; b < 8; b++) X.stack[a][b] = bw(ex(P.stack[a][b]));
   for (int i = 0; i <= 30; i++) {
-    X.bulge[i] = bw(P.bulge[i]);
-    X.internal_loop[i] = bw(P.internal_loop[i]);
-    X.ninio[i] = bw(P.max_ninio < i * P.ninio ? P.max_ninio : i * P.ninio);
+    X.bulge[i] = bw(ex(P.bulge[i]));
+    X.internal_loop[i] = bw(ex(P.internal_loop[i]));
+    X.ninio[i] = bw(std::min((double)P.max_ninio, i * ex(P.ninio)));
   }
   for (int s = 0; s <= SF_MAX_W + 1; s++)
-    X.hp_init[s] = (s <= 30) ? bw(P.hairpin[s]) : bw(P.hairpin[30]) * exp(-(P.lxc * log(s / 30.)) * 10. / kT);
+    X.hp_init[s] = (s <= 30) ? bw(ex(P.hairpin[s])) : bw(ex(P.hairpin[30])) * exp(-(P.lxc * log(s / 30.)) * 10. / kT);
   for (int t = 0; t < 8; t++)
     for (int a = 0; a < 5; a++) {
-      X.dangle5[t][a] = bws(P.dangle5[t][a]);
-      X.dangle3[t][a] = bws(P.dangle3[t][a]);
+      X.dangle5[t][a] = bws(ex(P.dangle5[t][a]));
+      X.dangle3[t][a] = bws(ex(P.dangle3[t][a]));
       for (int b = 0; b < 5; b++) {
-        X.mismatchI[t][a][b] = bw(P.mismatchI[t][a][b]);
-        X.mismatchH[t][a][b] = bw(P.mismatchH[t][a][b]);
-        X.mismatch1nI[t][a][b] = bw(P.mismatch1nI[t][a][b]);
-        X.mismatch23I[t][a][b] = bw(P.mismatch23I[t][a][b]);
-        X.mismatchM[t][a][b] = bws(P.mismatchM[t][a][b]);
-        X.mismatchExt[t][a][b] = bws(P.mismatchExt[t][a][b]);
+        X.mismatchI[t][a][b] = bw(ex(P.mismatchI[t][a][b]));
+        X.mismatchH[t][a][b] = bw(ex(P.mismatchH[t][a][b]));
+        X.mismatch1nI[t][a][b] = bw(ex(P.mismatch1nI[t][a][b]));
+        X.mismatch23I[t][a][b] = bw(ex(P.mismatch23I[t][a][b]));
+        X.mismatchM[t][a][b] = bws(ex(P.mismatchM[t][a][b]));
+        X.mismatchExt[t][a][b] = bws(ex(P.mismatchExt[t][a][b]));
       }
     }
   for (int a = 0; a < 8; a++)
     for (int b = 0; b < 8; b++)
       for (int c = 0; c < 5; c++)
         for (int d = 0; d < 5; d++) {
-          X.int11[a][b][c][d] = bw(P.int11[a][b][c][d]);
+          X.int11[a][b][c][d] = bw(ex(P.int11[a][b][c][d]));
           for (int e = 0; e < 5; e++) {
-            X.int21[a][b][c][d][e] = bw(P.int21[a][b][c][d][e]);
-            for (int f = 0; f < 5; f++) X.int22[a][b][c][d][e][f] = bw(P.int22[a][b][c][d][e][f]);
+            X.int21[a][b][c][d][e] = bw(ex(P.int21[a][b][c][d][e]));
+            for (int f = 0; f < 5; f++) X.int22[a][b][c][d][e][f] = bw(ex(P.int22[a][b][c][d][e][f]));
           }
         }
-  X.MLbase = bw(P.MLbase);
-  X.MLclosing = bw(P.MLclosing);
-  for (int t = 0; t < 8; t++) X.MLintern[t] = bw(P.MLintern[t]);
-  X.TermAU = bw(P.TerminalAU);
+  X.MLbase = bw(ex(P.MLbase));
+  X.MLclosing = bw(ex(P.MLclosing));
+  for (int t = 0; t < 8; t++) X.MLintern[t] = bw(ex(P.MLintern[t]));
+  X.TermAU = bw(ex(P.TerminalAU));
   for (int k = 0; k < SF_NSPECIAL; k++) {
-    X.tetra[k] = bw(P.tetra_E[k]);
-    X.tri[k] = bw(P.tri_E[k]);
-    X.hexa[k] = bw(P.hexa_E[k]);
+    X.tetra[k] = bw(ex(P.tetra_E[k]));
+    X.tri[k] = bw(ex(P.tri_E[k]));
+    X.hexa[k] = bw(ex(P.hexa_E[k]));
   }
   X.mlbase_pow[0] = 1.0;
   for (int k = 1; k <= SF_MAX_W + 1; k++) X.mlbase_pow[k] = X.mlbase_pow[k - 1] * X.MLbase;
@@ -450,16 +462,27 @@ int sf_device_name(char *buf, size_t n) {
 }
 
 int sf_params_load(const void *blob, size_t nbytes, double temperature_c) {
+  return sf_params_load_rescaled(blob, nbytes, temperature_c, nullptr, nullptr);
+}
+
+int sf_params_load_rescaled(const void *blob, size_t nbytes, double temperature_c, const void *blob_37c,
+                            const void *blob_enthalpy) {
   SF_ENTER();
   if (!blob || nbytes != sizeof(sf_params_blob)) return SF_ERR_BAD_PARAMS;
-  static sf_params_blob P;
+  if ((blob_37c == nullptr) != (blob_enthalpy == nullptr)) return SF_ERR_BAD_ARG;
+  static sf_params_blob P, P37, PdH;
   memcpy(&P, blob, sizeof P);
   if (P.magic != SF_PARAMS_MAGIC || P.version != SF_PARAMS_VERSION) return SF_ERR_BAD_PARAMS;
+  if (blob_37c) {
+    memcpy(&P37, blob_37c, sizeof P37);
+    memcpy(&PdH, blob_enthalpy, sizeof PdH);
+    if (P37.magic != SF_PARAMS_MAGIC || P37.version != SF_PARAMS_VERSION) return SF_ERR_BAD_PARAMS;
+  }
   if (fabs(P.temperature - temperature_c) > 1e-9) return SF_ERR_TEMPERATURE;
   static SfDevParams D;
   static SfDevParamsPF X;
   static SfFastParams F;
-  build_dev_params(P, D, X);
+  build_dev_params(P, D, X, blob_37c ? &P37 : nullptr, blob_37c ? &PdH : nullptr);
   D.max_pair_dist = g.max_bp_span > 0 ? g.max_bp_span - 1 : 0x7fffffff;
   sf_fast_build_params(D, F);
   g.fast_ok = F.fast_ok;

@@ -73,11 +73,25 @@ class ParamSet:
         self.rec37 = rec37 if rec37 is not None else rec
         self.lxc37 = float(rec["lxc"]) if lxc37 is None else lxc37
 
-    def blob(self):
+    @staticmethod
+    def _blob_of(rec):
         out = np.zeros((), dtype=BLOB_DTYPE)  # deterministic padding bytes (numpy leaves them undefined on copies)
         for f in BLOB_DTYPE.names:
-            out[f] = self.rec[f]
+            out[f] = rec[f]
         return out.tobytes()
+
+    def blob(self):
+        return self._blob_of(self.rec)
+
+    def rescale_blobs(self):
+        """(blob at 37 C, enthalpy blob) for sf_params_load_rescaled when this set was rescaled away from 37 C, else
+        (None, None): the Boltzmann weights are then built from the exact rescaled doubles, not from the truncated
+        integers of .blob() (ViennaRNA get_boltzmann_factors [EXT])."""
+        if self.dH is None or self.rec37 is self.rec or abs(self.temperature - 37.0) < 1e-12:
+            return None, None
+        dh = self.dH.copy()
+        dh["magic"], dh["version"] = self.rec["magic"], self.rec["version"]
+        return self._blob_of(self.rec37), self._blob_of(dh)
 
     @property
     def temperature(self):

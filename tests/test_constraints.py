@@ -237,6 +237,28 @@ def test_temperature_rescale_end_to_end(emul, oracle):
         emul.set_temperature(25)
         e25 = emul.mfe_batch([seq[:30], seq[30:60]])
         assert list(e25) == [oracle.mfe(seq[:30])[1], oracle.mfe(seq[30:60])[1]]
+        # Boltzmann weights at 25 C come from the un-truncated rescaled doubles (ViennaRNA get_boltzmann_factors [EXT]),
+        # the MFE tables from the truncated integers.  -kT ln Z is monotone in every table entry, so the exact ensemble
+        # energy lies between those of the all-floor and the all-ceil integer tables; the truncated tables alone
+        # (sf_params_load, no 37 C / enthalpy records) give a slightly different number.
+        p25 = p.at_temperature(25)
+        wins = [seq[:30], seq[30:60], seq[17:47]]
+        exact = emul.pf_batch(wins)["dG"]
+        assert np.allclose(exact, [oracle.pf(w)["dG"] for w in wins], rtol=0, atol=1e-8)
+        tempf = (25 + 273.15) / 310.15
+        bounds = {}
+        for name, fn in (("floor", np.floor), ("ceil", np.ceil)):
+            rec = p25.rec.copy()
+            for f in params._RESCALED:
+                g37, dh = p.rec37[f].astype(np.float64), p.dH[f].astype(np.float64)
+                rec[f] = np.where(np.abs(p.rec37[f]) >= params.INF, p.rec37[f], fn(dh - (dh - g37) * tempf)).astype(np.int64)
+            emul.load_params(params.ParamSet(rec, "bound-" + name))
+            bounds[name] = emul.pf_batch(wins)["dG"]
+        assert (bounds["floor"] <= exact + 1e-9).all() and (exact <= bounds["ceil"] + 1e-9).all()
+        assert (bounds["ceil"] - bounds["floor"] < 0.5).all()
+        emul.load_params(params.ParamSet(p25.rec.copy(), "truncated-only"))
+        trunc = emul.pf_batch(wins)["dG"]
+        assert 0 < np.abs(trunc - exact).max() < 0.2
         emul.load_params(base)
         with pytest.raises(NotImplementedError):
             emul.set_temperature(25)  # the reconstructed set has no enthalpies

@@ -183,6 +183,7 @@ void build_dev_params(const sf_params_blob &P, SfDevParams &D, SfDevParamsPF &X,
     X.tri[k] = bw(ex(P.tri_E[k]));
     X.hexa[k] = bw(ex(P.hexa_E[k]));
   }
+  for (int u = 2; u <= SF_MAXLOOP; u++) X.il1n[u] = X.internal_loop[u] * X.ninio[u - 2];
   X.mlbase_pow[0] = 1.0;
   for (int k = 1; k <= SF_MAX_W + 1; k++) X.mlbase_pow[k] = X.mlbase_pow[k - 1] * X.MLbase;
   // MFE model: dangle / multiloop / exterior mismatch terms are stored as min(0, x), as ViennaRNA's get_scaled_params

@@ -30,4 +30,5 @@ struct SfDevParamsPF {
   double MLbase, MLclosing, MLintern[8], TermAU;
   double tetra[SF_NSPECIAL], tri[SF_NSPECIAL], hexa[SF_NSPECIAL];
   double mlbase_pow[SF_MAX_W + 2];  // MLbase^k
+  double il1n[32];                  // internal_loop[u] * ninio[u - 2], u = 2..30: the size weight of a 1 x n loop (0 elsewhere)
 };

@@ -51,6 +51,24 @@
 #define SF_LANE_TABLE(name, L, expr) int name; { const int L = threadIdx.x & 63; name = (expr); asm volatile("" : "+v"(name)); }
 #define SF_LANE_GET(name, idx) __builtin_amdgcn_readlane(name, idx)
 #endif
+// Sizes UHI down to ULO in batches of NB: LOAD (fills qa[t], fa[t], da[t], wa[t] for size u) for a whole batch, then USE for
+// the same sizes in the same order.  The arithmetic and its order are those of the plain loop; the fences (SF_SCHED_FENCE, sf_launch.h) keep the
+// compiler from re-interleaving the two phases (it then waits for nearly every LDS read where it is issued).
+#define SF_PFL_BATCHES(UHI, ULO, NB, LOAD, USE)                                   \
+  _Pragma("unroll") for (int ub_ = (UHI); ub_ >= (ULO); ub_ -= (NB)) {            \
+    double qa[NB], fa[NB], da[NB], wa[NB];                                        \
+    (void)fa;                                                                     \
+    SF_SCHED_FENCE();                                                             \
+    _Pragma("unroll") for (int t = 0; t < (NB); t++) {                            \
+      const int u = ub_ - t;                                                      \
+      if (u >= (ULO)) LOAD                                                        \
+    }                                                                             \
+    SF_SCHED_FENCE();                                                             \
+    _Pragma("unroll") for (int t = 0; t < (NB); t++) {                            \
+      const int u = ub_ - t;                                                      \
+      if (u >= (ULO)) USE                                                         \
+    }                                                                             \
+  }
 // packed neighbour codes: bits 0-9 code*25 (row offset into a 25x25 weight table), 12-16 code, 20-22 nucleotide
 #define SF_PK_ROW(p) ((p) & 0x3ff)
 #define SF_PK_CODE(p) (((p) >> 12) & 31)
@@ -60,7 +78,7 @@
 // pairs: a byte each for positions 0..W+1)
 __host__ __device__ inline size_t sf_pfl_lds_bytes(int W, bool hc = false) {
   const size_t NC = (size_t)(W - 4) * (W - 3) / 2, RP = W + 2 * SF_PFL_PAD, VW = W + 8;
-  const size_t dbl = 2 * NC + 12 * RP + 3 * 625 + 2 * VW + 8 + 6 * VW + 7 * VW + (W + 2) + (W + 3) + 16 + 4 * 32 + (W + 8);
+  const size_t dbl = 2 * NC + 12 * RP + 3 * 625 + 2 * VW + 8 + 6 * VW + 7 * VW + (W + 2) + (W + 3) + 16;
   return dbl * sizeof(double) + 2 * (size_t)(W + 2) * sizeof(int) + (size_t)(W + 8) + 64 + (hc ? (size_t)((3 * (W + 2) + 7) & ~7) : 0);
 }
 // doubles per workgroup of the shared-inside state: qb, qm, derived buffers, qm1, 27 registers per centre slot
@@ -122,12 +140,11 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
   double *q5 = ZP + 7 * VW;       // [W+2]
   double *q3 = q5 + (W + 2);      // [W+3]
   double *red = q3 + (W + 3);     // [16]
-  double *WN = red + 16;          // ninio[32]
-  double *WB = WN + 32;           // bulge[32]
-  double *WIL = WB + 32;          // internal_loop[32]
-  double *WIL1N = WIL + 32;       // internal_loop[u] * ninio[u-2]
-  double *MLB = WIL1N + 32;       // MLbase^a, [W+8]
-  int *FWD = (int *)(MLB + (W + 8));  // [W+2]  packed code of (S[x], S[x+1])
+  // size weights and MLbase^a: the same for every lane — scalar loads from the parameter block (they used to be LDS copies read
+  // with broadcast reads: a third of the size loops' LDS instructions)
+  const double *const WN = X->ninio, *const WB = X->bulge, *const WIL = X->internal_loop, *const WIL1N = X->il1n;
+  const double *const MLB = X->mlbase_pow;
+  int *FWD = (int *)(red + 16);  // [W+2]  packed code of (S[x], S[x+1])
   int *BWD = FWD + (W + 2);           // [W+2]  packed code of (S[x], S[x-1])
   uint8_t *S = (uint8_t *)(BWD + (W + 2));  // [W+8]
   uint8_t *PT8 = S + (W + 8);               // [64] pair type of two nucleotide codes
@@ -148,13 +165,6 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
   const int maxd = D->max_pair_dist;
   // speculative (discarded or zero-weighted) reads below may land anywhere in the tables: keep them finite
   for (int x = tid; x < 2 * NC; x += SF_PFL_NT) QB[x] = 0.0;
-  if (tid < 32) {
-    WN[tid] = tid <= SFD_MAXLOOP ? X->ninio[tid] : 0.0;
-    WB[tid] = tid <= SFD_MAXLOOP ? X->bulge[tid] : 0.0;
-    WIL[tid] = tid <= SFD_MAXLOOP ? X->internal_loop[tid] : 0.0;
-    WIL1N[tid] = (tid >= 2 && tid <= SFD_MAXLOOP) ? X->internal_loop[tid] * X->ninio[tid - 2] : 0.0;
-  }
-  for (int x = tid; x < W + 8; x += SF_PFL_NT) MLB[x] = X->mlbase_pow[x];
   if (tid < 64) PT8[tid] = (uint8_t)D->pair[tid >> 3][tid & 7];
 
   const bool shared = SH;  // (a template parameter: the stand-alone instantiation carries none of the extra state)
@@ -255,12 +265,17 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
         int off = DOFF(a0 - 1), st = W - (a0 - 1);  // DOFF(a-1) and its increment
         for (int a = a0; a < 5 + 8 * b1; a += 8) {
           double t0 = 0.0, t1 = 0.0;
+          double mb[8], qv[8], rv[8];
+#pragma unroll
+          for (int t = 0; t < 8; t++) {
+            mb[t] = MLB[a + t]; qv[t] = qmr[off]; rv[t] = q1[a + t];
+            off += st--;
+          }
+          SF_SCHED_FENCE();
 #pragma unroll
           for (int t = 0; t < 8; t += 2) {
-            t0 += (MLB[a + t] + qmr[off]) * q1[a + t];
-            off += st--;
-            t1 += (MLB[a + t + 1] + qmr[off]) * q1[a + t + 1];
-            off += st--;
+            t0 += (mb[t] + qv[t]) * rv[t];
+            t1 += (mb[t + 1] + qv[t + 1]) * rv[t + 1];
           }
           m += t0;
           m2 += t1;
@@ -282,11 +297,13 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
           // Straight-line: family-A values are loaded speculatively (column clamped to an existing one) and
           // dropped by a select when the inner span would be < TURN+1; family-B values are 0 there by
           // themselves.  Sizes beyond umax therefore stay exactly 0 and need no separate bookkeeping.
-#pragma unroll
-          for (int u = 30; u >= 6; --u) {
-            const double a = qbA[SF_LANE_GET(tcol, u - 1)] * fI[SF_PK_ROW(SF_LANE_GET(tpk, u - 1))];
-            H[u - 4] = H[u - 6] + ((u <= umax ? a : 0.0) + dI3[u - 1]) * WN[u - 4];
-          }
+          SF_PFL_BATCHES(30, 6, 9, {
+            qa[t] = qbA[SF_LANE_GET(tcol, u - 1)]; fa[t] = fI[SF_PK_ROW(SF_LANE_GET(tpk, u - 1))];
+            da[t] = dI3[u - 1]; wa[t] = WN[u - 4];
+          }, {
+            const double a = qa[t] * fa[t];
+            H[u - 4] = H[u - 6] + ((u <= umax ? a : 0.0) + da[t]) * wa[t];
+          })
           {
             const double a = qbA[SF_LANE_GET(tcol, 4)] * fI[SF_PK_ROW(SF_LANE_GET(tpk, 4))];
             H[1] = ((umax >= 5 ? a : 0.0) + dI3[4]) * WN[1];
@@ -333,13 +350,16 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
           const double *dB1 = DERP(2, j - 1) + i + 1;
           const double *qbA = QB + i;  // row i+1
           double gb = 0.0, gb2 = 0.0;
-#pragma unroll
-          for (int u = 2; u <= 30; ++u) {
-            const double ta_ = (sp * SF_PK_NT(SF_LANE_GET(tpk, u + 1)) == 6) ? 1.0 : xTAU;  // C-G / G-C: no terminal penalty
-            const double ab = qbA[SF_LANE_GET(tcol, u + 1)] * ta_;
-            const double t = ((u <= umax ? ab : 0.0) + dB1[u]) * WB[u];
-            if (u & 1) gb2 += t; else gb += t;
-          }
+          SF_PFL_BATCHES(30, 2, 10, {
+            const int u_ = 32 - u;  // ascending sizes 2..30, as the sums were always accumulated
+            qa[t] = qbA[SF_LANE_GET(tcol, u_ + 1)]; da[t] = dB1[u_]; wa[t] = WB[u_]; fa[t] = 0.0;
+          }, {
+            const int u_ = 32 - u;
+            const double ta_ = (sp * SF_PK_NT(SF_LANE_GET(tpk, u_ + 1)) == 6) ? 1.0 : xTAU;  // C-G / G-C: no terminal penalty
+            const double ab = qa[t] * ta_;
+            const double tt = ((u_ <= umax ? ab : 0.0) + da[t]) * wa[t];
+            if (u_ & 1) gb2 += tt; else gb += tt;
+          })
           ZP[VW + i] = (gb + gb2) * (type > 2 ? xTAU : 1.0);
         }
         if (qvalid) ZP[4 * VW + i] = qm_part(0);
@@ -353,12 +373,16 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
           const double *f1N = FAC + 625 + SF_PK_CODE(BWD[i + 2]);
           const double *qbA = QB + i + 1;  // row i+2
           double g1 = 0.0, g2 = 0.0;
-#pragma unroll
-          for (int u = 4; u <= 30; ++u) {
-            const double an = qbA[SF_LANE_GET(tcol, u)] * f1N[SF_PK_ROW(SF_LANE_GET(tpk, u))];
-            const double t = ((u <= umax ? an : 0.0) + d1N2[u]) * WIL1N[u];
-            if (u & 1) g2 += t; else g1 += t;
-          }
+          SF_PFL_BATCHES(30, 4, 9, {
+            const int u_ = 34 - u;  // ascending sizes 4..30
+            qa[t] = qbA[SF_LANE_GET(tcol, u_)]; fa[t] = f1N[SF_PK_ROW(SF_LANE_GET(tpk, u_))];
+            da[t] = d1N2[u_]; wa[t] = WIL1N[u_];
+          }, {
+            const int u_ = 34 - u;
+            const double an = qa[t] * fa[t];
+            const double tt = ((u_ <= umax ? an : 0.0) + da[t]) * wa[t];
+            if (u_ & 1) g2 += tt; else g1 += tt;
+          })
           // mismatch1nI[type][S[i+1]][S[j-1]]: the family-A table read with the roles of row and column swapped
           ZP[2 * VW + i] = (g1 + g2) * FAC[625 + SF_PK_ROW(FWD[i]) + SF_PK_CODE(BWD[j])];
         }
@@ -373,12 +397,17 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
           int off = 0, st = W - 4;  // DOFF(a-2) and its increment, a = 6
           for (int a = SFD_TURN + 3; a <= d - SFD_TURN - 2; a += 8) {
             double t0 = 0.0, t1 = 0.0;
+            double qv[8], rv[8];
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+              qv[t] = qmr[off]; rv[t] = q1[a + t];
+              off += st--;
+            }
+            SF_SCHED_FENCE();
 #pragma unroll
             for (int t = 0; t < 8; t += 2) {
-              t0 += qmr[off] * q1[a + t];
-              off += st--;
-              t1 += qmr[off] * q1[a + t + 1];
-              off += st--;
+              t0 += qv[t] * rv[t];
+              t1 += qv[t + 1] * rv[t + 1];
             }
             ml += t0;
             ml1 += t1;
@@ -525,11 +554,26 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
         const int mmid = mlo + ((len >> 1) & ~3), m3q = mmid + ((sfd_max(W + 1 - mmid, 0) >> 1) & ~3);
         int m = part == 0 ? mlo : (part == 1 ? mmid : m3q);
         const int mhi = part == 0 ? mmid - 1 : (part == 1 ? m3q - 1 : W);
+        // (four terms per trip, their reads issued together; the neighbour codes — the address of a term's weight — are
+        // fetched one trip ahead)
+        int bw[4];
+#pragma unroll
+        for (int t = 0; t < 4; t++) bw[t] = BWD[sfd_min(m + t, W)];
         for (; m + 3 <= mhi; m += 4) {
-          r1 += QBC(k, m) * fW[SF_PK_ROW(BWD[m])] * QMD(m - 1 - l, l) +
-                QBC(k, m + 2) * fW[SF_PK_ROW(BWD[m + 2])] * QMD(m + 1 - l, l);
-          r1b += QBC(k, m + 1) * fW[SF_PK_ROW(BWD[m + 1])] * QMD(m - l, l) +
-                 QBC(k, m + 3) * fW[SF_PK_ROW(BWD[m + 3])] * QMD(m + 2 - l, l);
+          double q[4], f[4], g[4];
+          int bn[4];
+#pragma unroll
+          for (int t = 0; t < 4; t++) {
+            q[t] = QBC(k, m + t);
+            f[t] = fW[SF_PK_ROW(bw[t])];
+            g[t] = QMD(m + t - 1 - l, l);
+            bn[t] = BWD[sfd_min(m + 4 + t, W)];
+          }
+          SF_SCHED_FENCE();
+          r1 += q[0] * f[0] * g[0] + q[2] * f[2] * g[2];
+          r1b += q[1] * f[1] * g[1] + q[3] * f[3] * g[3];
+#pragma unroll
+          for (int t = 0; t < 4; t++) bw[t] = bn[t];
         }
         for (; m <= mhi; m++) r1 += QBC(k, m) * fW[SF_PK_ROW(BWD[m])] * QMD(m - 1 - l, l);
         return r1 + r1b;
@@ -545,13 +589,17 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
 #pragma unroll
             for (int u = 0; u < 27; u++) H[u] = 0.0;
           } else {
-#pragma unroll
-            for (int u = 30; u >= 6; --u) {
-              const double a = qbA[SF_LANE_GET(tcol, u - 1)] * fI[SF_PK_ROW(SF_LANE_GET(tpk, u - 1))];
+            // (reads of a batch of sizes are issued together, then used: left to itself the compiler waits for almost
+            // every LDS read on the spot — ~40 round trips in this block alone, and the column is nothing but such chains)
+            SF_PFL_BATCHES(30, 6, 9, {
+              qa[t] = qbA[SF_LANE_GET(tcol, u - 1)]; fa[t] = fI[SF_PK_ROW(SF_LANE_GET(tpk, u - 1))];
+              da[t] = dI3[1 - u]; wa[t] = WN[u - 4];
+            }, {
+              const double a = qa[t] * fa[t];
               const double e1 = (r3 && l + u - 1 <= W) ? a : 0.0;  // u1 = 2
-              const double e2 = c3 ? dI3[1 - u] : 0.0;             // u2 = 2
-              H[u - 4] = H[u - 6] + (e1 + e2) * WN[u - 4];
-            }
+              const double e2 = c3 ? da[t] : 0.0;                  // u2 = 2
+              H[u - 4] = H[u - 6] + (e1 + e2) * wa[t];
+            })
             {
               const double a = qbA[SF_LANE_GET(tcol, 4)] * fI[SF_PK_ROW(SF_LANE_GET(tpk, 4))];
               const double e1 = (r3 && l + 4 <= W) ? a : 0.0;
@@ -610,13 +658,16 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
           const double *dB1 = DERP(2, l + 1) + k - 1;
           const double *qbA = QB + (k > 1 ? k - 2 : 0);  // row k-1 (row 1 for speculative reads)
           double gb = 0.0, gb2 = 0.0;
-#pragma unroll
-          for (int u = 2; u <= 30; ++u) {
-            const double ab = qbA[SF_LANE_GET(tcol, u + 1)] * ((sp1 * SF_PK_NT(SF_LANE_GET(tpk, u + 1)) == 6) ? 1.0 : xTAU);
-            const double b1 = (l + 1 + u <= W) ? ab : 0.0;  // u1 = 0
-            const double t = (b1 + dB1[-u]) * WB[u];        // u2 = 0
-            if (u & 1) gb2 += t; else gb += t;
-          }
+          SF_PFL_BATCHES(30, 2, 10, {
+            const int u_ = 32 - u;  // ascending sizes 2..30, as the sums were always accumulated
+            qa[t] = qbA[SF_LANE_GET(tcol, u_ + 1)]; da[t] = dB1[-u_]; wa[t] = WB[u_]; fa[t] = 0.0;
+          }, {
+            const int u_ = 32 - u;
+            const double ab = qa[t] * ((sp1 * SF_PK_NT(SF_LANE_GET(tpk, u_ + 1)) == 6) ? 1.0 : xTAU);
+            const double b1 = (l + 1 + u_ <= W) ? ab : 0.0;  // u1 = 0
+            const double tt = (b1 + da[t]) * wa[t];          // u2 = 0
+            if (u_ & 1) gb2 += tt; else gb += tt;
+          })
           ZP[VW + k] = (gb + gb2) * (type > 2 ? xTAU : 1.0);  // rtype(type) > 2 <=> type > 2
           ZP[4 * VW + k] = r1_part(0);
         }
@@ -632,14 +683,18 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
           const double *f1N = FAC + 625 + SF_PK_CODE(FWD[kr2]);
           const double *qbA = QB + kr2 - 1;
           double g1 = 0.0, g2 = 0.0;
-#pragma unroll
-          for (int u = 4; u <= 30; ++u) {
-            const double an = qbA[SF_LANE_GET(tcol, u)] * f1N[SF_PK_ROW(SF_LANE_GET(tpk, u))];
-            const double n1 = (r2 && l + u <= W) ? an : 0.0;  // u1 = 1
-            const double n2 = c2 ? d1N2[-u] : 0.0;            // u2 = 1
-            const double t = (n1 + n2) * WIL1N[u];
-            if (u & 1) g2 += t; else g1 += t;
-          }
+          SF_PFL_BATCHES(30, 4, 9, {
+            const int u_ = 34 - u;  // ascending sizes 4..30
+            qa[t] = qbA[SF_LANE_GET(tcol, u_)]; fa[t] = f1N[SF_PK_ROW(SF_LANE_GET(tpk, u_))];
+            da[t] = d1N2[-u_]; wa[t] = WIL1N[u_];
+          }, {
+            const int u_ = 34 - u;
+            const double an = qa[t] * fa[t];
+            const double n1 = (r2 && l + u_ <= W) ? an : 0.0;  // u1 = 1
+            const double n2 = c2 ? da[t] : 0.0;                // u2 = 1
+            const double tt = (n1 + n2) * wa[t];
+            if (u_ & 1) g2 += tt; else g1 += tt;
+          })
           ZP[2 * VW + k] = (g1 + g2) * w1n;
           ZP[6 * VW + k] = r1_part(2);
         }
@@ -656,12 +711,17 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
             int off = -6, st = W - 5;  // DOFF(a-2) - a and its increment, a = 6
             for (int a = 6; a <= k - 1; a += 8) {
               double t0 = 0.0, t1 = 0.0;
+              double mb[8], rv[8], qv[8], sv8[8];
+#pragma unroll
+              for (int t = 0; t < 8; t++) {
+                mb[t] = MLB[a + t - 1]; rv[t] = r1p[-a - t]; qv[t] = qmr[off]; sv8[t] = r01p[-a - t];
+                off += st--;
+              }
+              SF_SCHED_FENCE();
 #pragma unroll
               for (int t = 0; t < 8; t += 2) {
-                t0 += MLB[a + t - 1] * r1p[-a - t] + qmr[off] * r01p[-a - t];
-                off += st--;
-                t1 += MLB[a + t] * r1p[-a - t - 1] + qmr[off] * r01p[-a - t - 1];
-                off += st--;
+                t0 += mb[t] * rv[t] + qv[t] * sv8[t];
+                t1 += mb[t + 1] * rv[t + 1] + qv[t + 1] * sv8[t + 1];
               }
               ms += t0;
               ms2 += t1;

@@ -78,7 +78,7 @@
 // pairs: a byte each for positions 0..W+1)
 __host__ __device__ inline size_t sf_pfl_lds_bytes(int W, bool hc = false) {
   const size_t NC = (size_t)(W - 4) * (W - 3) / 2, RP = W + 2 * SF_PFL_PAD, VW = W + 8;
-  const size_t dbl = 2 * NC + 12 * RP + 3 * 625 + 2 * VW + 8 + 6 * VW + 7 * VW + (W + 2) + (W + 3) + 16;
+  const size_t dbl = 2 * NC + 12 * RP + 3 * 625 + 2 * VW + 8 + 6 * VW + 7 * VW + (W + 2) + (W + 3) + 16 + (W + 8);
   return dbl * sizeof(double) + 2 * (size_t)(W + 2) * sizeof(int) + (size_t)(W + 8) + 64 + (hc ? (size_t)((3 * (W + 2) + 7) & ~7) : 0);
 }
 // doubles per workgroup of the shared-inside state: qb, qm, derived buffers, qm1, 27 registers per centre slot
@@ -144,7 +144,8 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
   // with broadcast reads: a third of the size loops' LDS instructions)
   const double *const WN = X->ninio, *const WB = X->bulge, *const WIL = X->internal_loop, *const WIL1N = X->il1n;
   const double *const MLB = X->mlbase_pow;
-  int *FWD = (int *)(red + 16);  // [W+2]  packed code of (S[x], S[x+1])
+  double *ZS = red + 16;          // [W+8] zeros, never written: the "column" beyond the window's end in the outside pass
+  int *FWD = (int *)(ZS + (W + 8));  // [W+2]  packed code of (S[x], S[x+1])
   int *BWD = FWD + (W + 2);           // [W+2]  packed code of (S[x], S[x-1])
   uint8_t *S = (uint8_t *)(BWD + (W + 2));  // [W+8]
   uint8_t *PT8 = S + (W + 8);               // [64] pair type of two nucleotide codes
@@ -165,6 +166,7 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
   const int maxd = D->max_pair_dist;
   // speculative (discarded or zero-weighted) reads below may land anywhere in the tables: keep them finite
   for (int x = tid; x < 2 * NC; x += SF_PFL_NT) QB[x] = 0.0;
+  for (int x = tid; x < W + 8; x += SF_PFL_NT) ZS[x] = 0.0;
   if (tid < 64) PT8[tid] = (uint8_t)D->pair[tid >> 3][tid & 7];
 
   const bool shared = SH;  // (a template parameter: the stand-alone instantiation carries none of the extra state)
@@ -528,6 +530,10 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
       FAC[625 + e] = t ? X->mismatch1nI[t][a1][b1] : 0.0;
       FAC[1250 + e] = t ? X->MLclosing * sfx_mlstem(X, sfd_rtype(t), b1, a1) : 0.0;
     }
+    // the derived buffers of columns W+1 .. W+3 are read as zeros (the inside values they hold were saved above if the next
+    // window wants them); a column beyond the window's end in qb is the zero strip: no test per loop size for either
+    for (int x = tid; x < 12 * RP; x += SF_PFL_NT) DER[x] = 0.0;
+    const int ZOFF = (int)(ZS - QB);
     __syncthreads();
 
     // ================= outside: columns l descending =================
@@ -539,11 +545,12 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
       const int k = s - l, d = l - k;
       const bool valid = (k >= 1) && (d >= SFD_TURN + 1);
       const bool inner = (k > 1) && (l < W);
+      const double qbkl = (valid && team != 0) ? QBC(k, l) : 0.0;  // qb[k,l]: replaced by ob[k,l] at the end of this column
       const double *R1c = RV + (2 + (l & 1)) * VW, *R01c = RV + (4 + (l & 1)) * VW, *R0c = RV + (l & 1) * VW;
       double *R0n = RV + ((l & 1) ^ 1) * VW, *R1n = RV + (2 + ((l & 1) ^ 1)) * VW, *R01n = RV + (4 + ((l & 1) ^ 1)) * VW;
       // lane tables, entry L: column min(l+L, W)
       SF_LANE_TABLE(tpk, L, BWD[sfd_min(l + L, W)]);
-      SF_LANE_TABLE(tcol, L, COFF(sfd_min(l + L, W)));
+      SF_LANE_TABLE(tcol, L, l + L <= W ? COFF(l + L) : ZOFF);
       const bool r3 = k - 3 >= 1, r2 = k - 2 >= 1;  // the row exists
       // R1 of the next column l-1, row k: closers (k, m), m >= l+5, right part qm[l, m-1]; the range of m is the
       // same for every row: team 1 takes its first half, teams 3 and 2 a quarter each (shares from the measured load of the teams)
@@ -581,7 +588,6 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
       if (team == 0) {
         if (valid) {
           const double *dI3 = DERP(0, l + 3) + k;
-          const bool c3 = l + 3 <= W;  // the column exists (its slot holds outside values)
           const int kr3 = r3 ? k - 3 : 1;  // row for speculative reads
           const double *fI = FAC + SF_PK_CODE(FWD[kr3]);
           const double *qbA = QB + kr3 - 1;
@@ -596,17 +602,15 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
               da[t] = dI3[1 - u]; wa[t] = WN[u - 4];
             }, {
               const double a = qa[t] * fa[t];
-              const double e1 = (r3 && l + u - 1 <= W) ? a : 0.0;  // u1 = 2
-              const double e2 = c3 ? da[t] : 0.0;                  // u2 = 2
-              H[u - 4] = H[u - 6] + (e1 + e2) * wa[t];
+              const double e1 = r3 ? a : 0.0;  // u1 = 2
+              H[u - 4] = H[u - 6] + (e1 + da[t]) * wa[t];  // da: u2 = 2
             })
             {
               const double a = qbA[SF_LANE_GET(tcol, 4)] * fI[SF_PK_ROW(SF_LANE_GET(tpk, 4))];
-              const double e1 = (r3 && l + 4 <= W) ? a : 0.0;
-              const double e2 = c3 ? dI3[-4] : 0.0;
-              H[1] = (e1 + e2) * WN[1];
+              const double e1 = r3 ? a : 0.0;
+              H[1] = (e1 + dI3[-4]) * WN[1];
             }
-            H[0] = c3 ? dI3[-3] * WN[0] : 0.0;
+            H[0] = dI3[-3] * WN[0];
           }
           const int type = OWN(k, l);
           // exterior term, then the small special loops with (k,l) as the INNER pair — branch-free as in the
@@ -664,8 +668,7 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
           }, {
             const int u_ = 32 - u;
             const double ab = qa[t] * ((sp1 * SF_PK_NT(SF_LANE_GET(tpk, u_ + 1)) == 6) ? 1.0 : xTAU);
-            const double b1 = (l + 1 + u_ <= W) ? ab : 0.0;  // u1 = 0
-            const double tt = (b1 + da[t]) * wa[t];          // u2 = 0
+            const double tt = (ab + da[t]) * wa[t];  // u1 = 0, u2 = 0
             if (u_ & 1) gb2 += tt; else gb += tt;
           })
           ZP[VW + k] = (gb + gb2) * (type > 2 ? xTAU : 1.0);  // rtype(type) > 2 <=> type > 2
@@ -678,7 +681,6 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
           const int sp1 = S[k - 1], sq1 = S[l + 1];
           const double w1n = X->mismatch1nI[rt][sq1][sp1];  // device memory: issued before the long sums below
           const double *d1N2 = DERP(1, l + 2) + k;
-          const bool c2 = l + 2 <= W;
           const int kr2 = r2 ? k - 2 : 1;
           const double *f1N = FAC + 625 + SF_PK_CODE(FWD[kr2]);
           const double *qbA = QB + kr2 - 1;
@@ -690,9 +692,8 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
           }, {
             const int u_ = 34 - u;
             const double an = qa[t] * fa[t];
-            const double n1 = (r2 && l + u_ <= W) ? an : 0.0;  // u1 = 1
-            const double n2 = c2 ? da[t] : 0.0;                // u2 = 1
-            const double tt = (n1 + n2) * wa[t];
+            const double n1 = r2 ? an : 0.0;  // u1 = 1
+            const double tt = (n1 + da[t]) * wa[t];  // da: u2 = 1
             if (u_ & 1) g2 += tt; else g1 += tt;
           })
           ZP[2 * VW + k] = (g1 + g2) * w1n;
@@ -732,28 +733,34 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
         }
       }
       __syncthreads();
-      if (team == 2 && valid) {
+      // The column's results, shared out: team 2 writes the tables the next column's loops read, team 1 the multiloop vectors,
+      // team 3 the pair probability and what hangs on it (each forms the cell's sum from the partial sums itself; qb[k,l],
+      // which team 2 overwrites here, was read before the barrier).
+      if (team != 0 && valid) {
         const int type = OWN(k, l);
-        const double qbkl = QBC(k, l);
         double o = 0.0;
         if (type && qbkl != 0.0) o = inner ? (ZP[k] + ZP[VW + k]) + (ZP[2 * VW + k] + ZP[3 * VW + k]) : ZP[k];
-        QBC(k, l) = o;
         const int fa = SF_PK_ROW(BWD[l]) + SF_PK_CODE(FWD[k]);  // (S[l], S[l-1]) x (S[k], S[k+1]): LDS, not device memory
-        DERP(0, l)[k] = type ? o * FAC[fa] : 0.0;
-        DERP(1, l)[k] = type ? o * FAC[625 + fa] : 0.0;
-        DERP(2, l)[k] = (type > 2) ? o * xTAU : o;
-        const double w = type ? o * FAC[1250 + fa] : 0.0;
-        const double r0 = w + xMLbase * R0c[k];
-        const double r1 = (ZP[5 * VW + k] + ZP[6 * VW + k]) + ZP[4 * VW + k];
-        R0n[k] = r0;
-        R1n[k] = r1;
-        R01n[k] = r0 + r1;
-        const double p = o * qbkl / Z;
-        mbd += p * (1.0 - p);
-        if (p > 0.5) {
-          cd += 1.0 - p;
-          if (centroid) { centroid[(size_t)fold * W1 + k - 1] = '('; centroid[(size_t)fold * W1 + l - 1] = ')'; }
-        } else cd += p;
+        if (team == 2) {
+          QBC(k, l) = o;
+          DERP(0, l)[k] = type ? o * FAC[fa] : 0.0;
+          DERP(1, l)[k] = type ? o * FAC[625 + fa] : 0.0;
+          DERP(2, l)[k] = (type > 2) ? o * xTAU : o;
+        } else if (team == 1) {
+          const double w = type ? o * FAC[1250 + fa] : 0.0;
+          const double r0 = w + xMLbase * R0c[k];
+          const double r1 = (ZP[5 * VW + k] + ZP[6 * VW + k]) + ZP[4 * VW + k];
+          R0n[k] = r0;
+          R1n[k] = r1;
+          R01n[k] = r0 + r1;
+        } else {
+          const double p = o * qbkl / Z;
+          mbd += p * (1.0 - p);
+          if (p > 0.5) {
+            cd += 1.0 - p;
+            if (centroid) { centroid[(size_t)fold * W1 + k - 1] = '('; centroid[(size_t)fold * W1 + l - 1] = ')'; }
+          } else cd += p;
+        }
       }
       __syncthreads();
     }

@@ -14,6 +14,18 @@
 #define SF_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 // the value must be computed by this point (keeps the arithmetic next to the loads that feed it)
 #define SF_PIN(x) asm volatile("" : "+v"(x))
+// A wave-uniform pointer into constant device memory whose value the optimiser has to take as given at this point: addresses
+// derived from it stay "base + immediate" at their loads (s_load / global_load saddr) instead of being hoisted out of the caller's
+// loops one 64-bit scalar pair per address — pairs that are then parked in the lanes of a VGPR and fetched back with two
+// v_readlane before every use (8-10 % of the vector instructions of the MFE kernel's main blocks were that).
+template <class T>
+__device__ __forceinline__ const T *sf_const_base(const T *p) {
+  const uintptr_t a = (uintptr_t)p;  // (readfirstlane: uniform by construction, but derived from threadIdx where the wave's diagonal is)
+  uintptr_t b = ((uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
+                (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+  asm volatile("" : "+s"(b));
+  return (const T *)(const __attribute__((address_space(4))) T *)b;
+}
 // v of lane l (l wave-uniform, known only at run time)
 #define SF_LANE_READ(v, l) __builtin_amdgcn_readlane((v), (l))
 // a value that is the same in every lane of the wave: tell the compiler (keeps derived index math scalar)

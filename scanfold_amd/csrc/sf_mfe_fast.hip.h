@@ -383,7 +383,10 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
   // sizes above it cost 32767 (round 2 built that copy per wave and step in LDS).
   // (G, the first four steps: every use sits behind its own size test — a scalar load there would be waited for on the
   // spot; that code keeps reading an LDS copy: measured 1 % faster at W = 200.)
-  const int16_t *const ubase = G ? X.uNIN : (CH ? X.F->uniG[sfd_max(sfd_min(d - 2 - (SFD_TURN + 1), 30), 0)] : X.F->uni);
+  // (Fc: the parameter block through sf_const_base — its tables are addressed "one scalar base + offset" at every load)
+  // (W > 128: measured 0.8 % slower with it, 1.5 % faster at W = 120 / 128 — profiles/r03/mfe_scalar_bases.txt)
+  const SfFastParams *const Fc = FOLD ? X.F : sf_const_base(X.F);
+  const int16_t *const ubase = G ? X.uNIN : (CH ? Fc->uniG[sfd_max(sfd_min(d - 2 - (SFD_TURN + 1), 30), 0)] : Fc->uni);
   const int16_t *const uNIN = ubase, *const uIL = ubase + 32, *const uBN = ubase + 64;
 // Word x of a row holds (CB[x], C1N[x+1]) — the two left-edge candidates of a size, CB at column 1 and C1N at column
 // 2, are then ONE word.  (SHIFT = false: (CB[x], C1N[x]), the layout until late in round 2.)
@@ -507,23 +510,23 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
       }
       if (!G || (UCAP >= 2 && umax >= 2)) {  // 1 x 1: (i+2, j-2)
         const unsigned t2r = RP[S[i + 2] * 8 + S[j - 2]];
-        eh = sfd_min(eh, CBAT(ROW(2) + i0 + 2) + X.F->int11T[((tq + t2r) * 5u + si1) * 5u + sj1]);
+        eh = sfd_min(eh, CBAT(ROW(2) + i0 + 2) + Fc->int11T[((tq + t2r) * 5u + si1) * 5u + sj1]);
       }
       if (!G || (UCAP >= 3 && umax >= 3)) {  // 1 x 2 and 2 x 1
         const int16_t *row = X.BN + 2 * (ROW(3) + i0);
         const unsigned ta = RP[S[i + 2] * 8 + S[j - 3]];  // (i+2, j-3), sq1 = S[j-2]
-        eh = sfd_min(eh, row[2 * 2] + X.F->int21a[(((tq + ta) * 5u + si1) * 5u + S[j - 2]) * 5u + sj1]);
+        eh = sfd_min(eh, row[2 * 2] + Fc->int21a[(((tq + ta) * 5u + si1) * 5u + S[j - 2]) * 5u + sj1]);
         const unsigned tb = RP[S[i + 3] * 8 + S[j - 2]];  // (i+3, j-2), sp1 = S[i+2]
-        eh = sfd_min(eh, row[2 * 3] + X.F->int21b[(((tb * 8u + type) * 5u + sj1) * 5u + si1) * 5u + S[i + 2]]);
+        eh = sfd_min(eh, row[2 * 3] + Fc->int21b[(((tb * 8u + type) * 5u + sj1) * 5u + si1) * 5u + S[i + 2]]);
       }
       if (!G || (UCAP >= 4 && umax >= 4)) {  // 2 x 2: (i+3, j-3)
         const unsigned t2r = RP[S[i + 3] * 8 + S[j - 3]];
         eh = sfd_min(eh, CBAT(ROW(4) + i0 + 3) +
-                             X.F->int22T[((((tq + t2r) * 5u + si1) * 5u + S[i + 2]) * 5u + S[j - 2]) * 5u + sj1]);
+                             Fc->int22T[((((tq + t2r) * 5u + si1) * 5u + S[i + 2]) * 5u + S[j - 2]) * 5u + sj1]);
       }
       if (!G || (UCAP >= 5 && umax >= 5)) {  // 2 x 3 and 3 x 2
         const int16_t *row = X.BN + 2 * (ROW(5) + i0);
-        const int m23 = X.t23[SF_TIDX(type, si1, sj1)] + X.F->L23;
+        const int m23 = X.t23[SF_TIDX(type, si1, sj1)] + Fc->L23;
         const int ta = RP[S[i + 3] * 8 + S[j - 4]];  // (i+3, j-4); sp1 = S[i+2], sq1 = S[j-3]
         eh = sfd_min(eh, row[2 * 3] + m23 + X.t23in[SF_TIDX(ta, S[j - 3], S[i + 2])]);
         const int tb = RP[S[i + 4] * 8 + S[j - 3]];  // (i+4, j-3); sp1 = S[i+3], sq1 = S[j-2]

@@ -54,6 +54,7 @@
 // work is small and the unbroken straight-line code is faster (measured: 20 / 24 / 28 / 36 -> 87.5 / 87.1 / 87.0 / 87.9 ms)
 #define SF_FAST_CHUNK_D0 36
 #define SF_FAST_SPLIT 1  // long diagonals: the idle second wave of a group takes part of the cell's work
+#define SF_FAST_DML2 1   // ... and the first runs the multiloop split two cells per lane, the lanes in chunks over the terms
 // split steps at W <= 128: 1 = ONE helper wave serves both diagonals of a step, on a compacted list of the cells that
 // can pair (3 of 8): the special / bulge / 1xn block runs once per step instead of twice
 // (W < SF_HELP_MERGE_MAXW only.  With folds handed out dynamically the merge measures +3.6 % at W=80, +2.3 % at W=100,
@@ -206,6 +207,7 @@ static inline __host__ __device__ SfFastLayout sf_fast_layout(int W, bool hc = f
   SfFastLayout L;
   int tri = (W - 4) * W - (W * (W - 1) / 2 - 6);  // sum_{d=4}^{W-1} (W-d)
   if (W > 128) tri = ((W + 3) / 2 - 3) * (W - 3);  // FOLD: (H-3) rows of S = W-3 entries (same area)
+  else if (W > 4) tri += (W - 4 + (W & 1)) >> 1;   // triangle: every diagonal starts at an even index (see FBASE)
   if (tri < 0) tri = 0;
   tri = (tri + 1) & ~1;
   L.tri = tri;
@@ -430,8 +432,12 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
     pub.tau = tau_in;
   }
 // first entry of diagonal dd.  Triangle without diagonals 0..3: sum_{k=4}^{dd-1} (W-k); FOLD: see the file header
+// (triangle: a diagonal of odd length W-dd is followed by one unused entry, so every diagonal starts at an even index and two
+// neighbouring cells (2p, 2p+1) of a diagonal are ONE aligned 32-bit word — what sf_fast_dml2 reads)
 #define FBASE(dd) (FOLD ? ((dd) <= (W + 3) / 2 ? ((dd)-4) * (W - 3) : (W - 1 - (dd)) * (W - 3) + (dd)-3) \
-                        : (((dd)-4) * W - ((dd) * ((dd)-1) / 2 - 6)))
+                        : (((dd)-4) * W - ((dd) * ((dd)-1) / 2 - 6) + (((dd)-4 + (W & 1)) >> 1)))
+// length of diagonal dd in that layout
+#define FLEN(dd) (W - (dd) + ((W - (dd)) & 1))
 // row of diagonal d-2-u in the rolling tables
 // (a v_readlane lane table for these offsets measured +1 % at W=120, -2 % at W=200, and is unsafe wherever the
 // build spills registers — see SF_UNI — so the scalar unit keeps computing them)
@@ -614,16 +620,21 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
     }
     dec = sfd_min(dec, dec2);
   } else {
-    // fML[i, i+m] = fML_tri[FBASE(m) + i0], fML[i+m+1, j] = fML_tri[FBASE(d-m-1) + i0+m+1].  Both offsets step by
-    // wave-uniform differences, FBASE(m+1)-FBASE(m) = W-m: inside a batch of eight terms each address is the
-    // previous one plus ONE uniform byte step (a single v_add with a scalar operand), the triangular part
-    // -k(k-1)/2 of the step sequence is a compile-time load offset (pointers rebased by 56 bytes to keep it >= 0).
-    // (a split step shares the terms between the waves of a cell: m = dml_lo .. min(dml_hi, d-5), wave-uniform)
+    // fML[i, i+m] = fML_tri[FBASE(m) + i0], fML[i+m+1, j] = fML_tri[FBASE(d-m-1) + i0+m+1].  From one term to the next the first
+    // offset grows by the length of diagonal m, the second shrinks by the length of diagonal d-m-2 less one — lengths
+    // that fall / rise by two every second diagonal (FLEN).  Inside a batch of eight terms (m0 even) each address is the
+    // previous one plus ONE of two uniform byte steps (they alternate: a single v_add with a scalar operand), the rest of
+    // the step sequence is a compile-time load offset:
+    //   first operand:  a_k = a_0 + k L0 - e_k - 2 pa (k >> 1),  L0 = FLEN(m0), pa = (W - m0) & 1, e = 0 0 0 2 4 8 12 18 (24)
+    //   second operand: b_k = b_0 - k (M - 1) - 2 g_k + q (k & 1),  M = W - (d-1-m0), q = M & 1, 2 g = 0 2 4 8 12 18 24 32 (40)
+    // (a split step shares the terms between the waves of a cell: m = dml_lo .. min(dml_hi, d-5), wave-uniform; dml_lo even)
     int m = dml_lo;
     const int mend = sfd_min(d - SFD_TURN - 2, dml_hi);
-    const char *pa = (const char *)(X.fML + i0 + FBASE(m)) - 56;                      // FBASE(4) = 0
-    const char *pb = (const char *)(X.fML + i0 + 1 + FBASE(d - m - 1) + m) - 56;
-    int sa = 2 * (W - m), sb = 2 * (W - d + m + 1);
+    const char *pa = (const char *)(X.fML + i0 + FBASE(m)) - 36;                      // FBASE(4) = 0
+    const char *pb = (const char *)(X.fML + i0 + 1 + FBASE(d - m - 1) + m) - 64;
+    const int par_a = (W - m) & 1, M0 = W - d + 1 + m, par_b = M0 & 1;
+    int sa0 = 2 * FLEN(m), sa1 = sa0 - 4 * par_a;               // after an even / odd term of the batch
+    int sb0 = 2 * (M0 - 1 - par_b), sb1 = 2 * (M0 - 1 + par_b);
     int dec2 = SF_FAST_BIG;
     // (Software-pipelining these batches on the split steps' main waves — the reads of batch t+1 in flight while batch t
     // is reduced, 16 more registers — measured 0.6 % slower at W = 120, 3-4 % at W = 100 / 128 in round 3, as the pipelined
@@ -632,12 +643,13 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
       int a[8], b[8];
 #pragma unroll
       for (int k = 0; k < 8; k++) {
-        a[k] = *(const int16_t *)(pa + (56 - k * (k - 1)));
-        b[k] = *(const int16_t *)(pb + (56 - k * (k - 1)));
-        pa += k < 7 ? sa : sa - 56;  // the last step also rebases for the next batch
-        pb -= k < 7 ? sb : sb + 56;
+        constexpr int E[8] = {0, 0, 0, 2, 4, 8, 12, 18}, G2[8] = {0, 2, 4, 8, 12, 18, 24, 32};
+        a[k] = *(const int16_t *)(pa + (36 - 2 * E[k]));
+        b[k] = *(const int16_t *)(pb + (64 - 2 * G2[k]));
+        pa += (k & 1) ? (k < 7 ? sa1 : sa1 - 48) : sa0;  // the last step also rebases for the next batch
+        pb -= (k & 1) ? (k < 7 ? sb1 : sb1 + 80) : sb0;
       }
-      sa -= 16; sb += 16;
+      sa0 -= 16; sa1 -= 16; sb0 += 16; sb1 += 16;
 #pragma unroll
       for (int k = 0; k < 8; k += 2) {
         dec = sfd_min(dec, a[k] + b[k]);
@@ -645,8 +657,9 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
       }
     }
     for (; m <= mend; m++) {
-      dec = sfd_min(dec, *(const int16_t *)(pa + 56) + *(const int16_t *)(pb + 56));
-      pa += sa; pb -= sb; sa -= 2; sb += 2;
+      dec = sfd_min(dec, *(const int16_t *)(pa + 36) + *(const int16_t *)(pb + 64));
+      pa += 2 * FLEN(m);
+      pb -= 2 * (FLEN(d - m - 2) - 1);
     }
     dec = sfd_min(dec, dec2);
   }
@@ -776,6 +789,81 @@ __device__ __forceinline__ int sf_wave_min(int v) {
   v = sfd_min(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xC, 0xF, false));  // row_bcast:31 -> rows 2,3
   return __builtin_amdgcn_readlane(v, 63);
 #endif
+}
+
+// the 32-bit value of the next lane (lane l gets lane l+1's; the last lane's result is unspecified)
+__device__ __forceinline__ uint32_t sf_wave_next(uint32_t v) {
+#ifdef SF_EMUL
+  return __shfl_down(v, 1);
+#else
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, false);  // wave_shl:1
+#endif
+}
+
+// Multiloop split of a WHOLE diagonal by one wave (split steps of the narrow kernel: the diagonal's n = W-d <= 62 cells are
+// all in this wave): dec[i] = min_{m=4}^{d-5} fML[i, i+m] + fML[i+m+1, j] for every cell, returned to the lane that owns the cell.
+// The one-cell-per-lane form keeps (W-d)/64 of the lanes busy and issues two 16-bit reads and ~4 vector instructions per
+// term and cell.  Here a lane takes TWO neighbouring cells (2p, 2p+1): their first operands are one aligned word of diagonal
+// m (every diagonal starts at an even index, FBASE), their second operands one word of diagonal d-1-m — aligned for odd m;
+// for even m they straddle two words, the lane's own and the next lane's (sf_wave_next, a DPP move: lane p+1 reads the word
+// that follows) — and sums / minima are packed int16 (saturating: INF + INF stays "none", sums of real energies are exact
+// below the overflow threshold that sends a fold to the int32 kernel anyway).  The n/2 pairs need at most 31 lanes (+ one
+// that only feeds its word to its neighbour), so the wave's 64 lanes form 2, 4 or 8 chunks (W-d <= 62 / 30 / 14) that share
+// the terms: chunk c takes T8 terms from m = 4 + c S (the last chunks clamped to end at the last term; a minimum does not
+// mind a term twice), and a butterfly over the chunks joins them.  Batches of eight terms starting at even m with the address
+// arithmetic of the one-cell loop (two alternating steps + compile-time offsets, here per lane).  d odd: the term m = d-5
+// (even, so that the batches can stop at an odd m) is done by every chunk on its own.
+template <int WT>
+__device__ __forceinline__ int sf_fast_dml2(const SfFastCtx &X, const int d, const int lane, const int i_own, const bool valid) {
+  constexpr bool FOLD = false;
+  const int W = WT ? WT : X.W;
+  const int n = W - d, npairs = (n + 1) >> 1;
+  const int lg = npairs <= 7 ? 3 : (npairs <= 15 ? 4 : 5);  // lanes per chunk = 1 << lg (pairs + at least one feeder lane)
+  const int NC = 64 >> lg;
+  const int q = lane & ((1 << lg) - 1), c = lane >> lg;
+  const int elast = (d & 1) ? d - 6 : d - 5;            // last term of the batched range (odd)
+  const int N = elast - 3;                              // terms 4 .. elast (an even number)
+  const int S = (((N + NC - 1) / NC) + 1) & ~1;         // a chunk's share, even
+  const int T8 = (S + 7) & ~7;                          // what it runs: whole batches
+  const int ms = sfd_min(4 + c * S, elast - T8 + 1);    // per lane (per chunk), even
+  const int ys = d - 1 - ms;
+  const int par_a = W & 1, M0 = W - ys, par_b = (W - d + 1) & 1;
+  const char *pa = (const char *)(X.fML + FBASE(ms) + 2 * q) - 36;
+  const char *pb = (const char *)(X.fML + FBASE(ys) + 2 * q + ms + 1) - 64;
+  int sa0 = 2 * (W - ms + par_a), sa1 = sa0 - 4 * par_a;
+  int sb0 = 2 * (M0 - 1 - par_b), sb1 = 2 * (M0 - 1 + par_b);
+  uint32_t acc0 = sf_pk(32767, 32767), acc1 = acc0;
+  for (int t = 0; t < T8; t += 8) {
+    uint32_t wa[8], wb[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      constexpr int E[8] = {0, 0, 0, 2, 4, 8, 12, 18}, G2[8] = {0, 2, 4, 8, 12, 18, 24, 32};
+      wa[k] = sf_ldw((const int16_t *)(pa + (36 - 2 * E[k])));
+      wb[k] = sf_ldw((const int16_t *)(pb + (64 - 2 * G2[k] - ((k & 1) ? 0 : 2))));  // even m: the word its first half ends
+      pa += (k & 1) ? (k < 7 ? sa1 : sa1 - 48) : sa0;
+      pb -= (k & 1) ? (k < 7 ? sb1 : sb1 + 80) : sb0;
+    }
+    sa0 -= 16; sa1 -= 16; sb0 += 16; sb1 += 16;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      uint32_t b = wb[k];
+      if (!(k & 1)) b = (sf_wave_next(b) << 16) | (b >> 16);
+      if (k & 1) acc1 = sf_pkmin(acc1, sf_pkadd(wa[k], b)); else acc0 = sf_pkmin(acc0, sf_pkadd(wa[k], b));
+    }
+  }
+  if (d & 1) {  // m = d-5: first operands on diagonal d-5, second on diagonal 4 from index 2q + d-4 (odd)
+    const uint32_t a = sf_ldw(X.fML + FBASE(d - 5) + 2 * q);
+    const uint32_t w = sf_ldw(X.fML + 2 * q + d - 5);
+    acc0 = sf_pkmin(acc0, sf_pkadd(a, (sf_wave_next(w) << 16) | (w >> 16)));
+  }
+  uint32_t acc = sf_pkmin(acc0, acc1);
+  acc = sf_pkmin(acc, __shfl_xor(acc, 32));
+  if (lg <= 4) acc = sf_pkmin(acc, __shfl_xor(acc, 16));
+  if (lg <= 3) acc = sf_pkmin(acc, __shfl_xor(acc, 8));
+  // the cell's owner fetches its pair's result (every chunk holds it now) and takes its half
+  const int i0 = valid ? i_own - 1 : 0;
+  const uint32_t r = __shfl(acc, i0 >> 1);
+  return (i0 & 1) ? sf_hi(r) : sf_lo(r);
 }
 
 // c[i,j] from the scratch (which may hold c + ExtLoop, see SfFastCtx::cg_ext)
@@ -1199,6 +1287,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
   // middle waves — the other waves of the group then work as helpers (see `split` below).
   constexpr int CENTRE = (NG == 256) ? 128 : 32;
   constexpr bool SHARE = SF_DML_HELPER_BIAS(NG) < 10000;  // the helper waves take part of the multiloop split
+  constexpr bool DML2 = (NG == 128) && SF_FAST_DML2;    // split steps: the main wave splits two cells per lane (sf_fast_dml2)
   const int OFFs = ((W + 1) >> 1) - CENTRE;                  // signed: v = tg + OFFs (mod NG)
   const int OFF = (NG > 64) ? (OFFs + NG) & (NG - 1) : 0;
   const int v = (tg + OFF) & (NG - 1);
@@ -1339,7 +1428,10 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
         else if (!split) sf_fast_cell<false, WT, SF_SEC_ALL, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
         else if (!helper) {
           if (SHARE) sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_DML | SF_SEC_PRE, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub, SFD_TURN + 1, dml_cut - 1);
-          else sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_DML | SF_SEC_PRE, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
+          else if (DML2) {
+            dec = sf_fast_dml2<WT>(X, d, tid & 63, i, valid);
+            sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_PRE, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
+          } else sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_DML | SF_SEC_PRE, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
         } else if (MERGE) {
           // Merged helper (W <= 128).  ONE helper wave serves both diagonals of the step: it works on the list of the
           // cells of d0 and d0+1 that can pair (build_list above; 3 of 8 cells, so ordinary sequences fit wave 1's 64
@@ -1448,6 +1540,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
     seq = next_seq;
   }
 #undef FBASE
+#undef FLEN
 }
 
 static inline hipError_t sf_fast_configure() {

@@ -217,10 +217,43 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
       const int wv = tid >> 6, ln = tid & 63;
       // k = step.  qb: new (i,j) = old (i+k,j+k), columns 5..W-k;  qm: new (d,i) = old (d,i+k)
       const int k = step, j0 = W - k + 1;  // j0: first column to compute
-      for (int jj = 5 + wv; jj <= W - k; jj += SF_PFL_NT / 64)
-        for (int ii = 1 + ln; ii <= jj - 4; ii += 64) QBC(ii, jj) = sv[COFF(jj + k) + ii + k - 1];
-      for (int dd = 4 + wv; dd <= W - k - 1; dd += SF_PFL_NT / 64)
-        for (int ii = 1 + ln; ii <= W - k - dd; ii += 64) QMD(dd, ii) = sv[SV_QM + DOFF(dd) + ii + k - 1];
+      // (four columns / diagonals of a wave at a time, their loads in flight together: one dependent global load per
+      // trip made this reload ~7 % of a resumed window)
+      constexpr int NWV = SF_PFL_NT / 64, RB = 4;
+      for (int j0b = 5 + wv; j0b <= W - k; j0b += RB * NWV) {
+        double v[RB][2];
+#pragma unroll
+        for (int b = 0; b < RB; b++)
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            const int jj = j0b + b * NWV, ii = 1 + ln + 64 * h;
+            v[b][h] = (jj <= W - k && ii <= jj - 4) ? sv[COFF(jj + k) + ii + k - 1] : 0.0;
+          }
+#pragma unroll
+        for (int b = 0; b < RB; b++)
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            const int jj = j0b + b * NWV, ii = 1 + ln + 64 * h;
+            if (jj <= W - k && ii <= jj - 4) QBC(ii, jj) = v[b][h];
+          }
+      }
+      for (int d0b = 4 + wv; d0b <= W - k - 1; d0b += RB * NWV) {
+        double v[RB][2];
+#pragma unroll
+        for (int b = 0; b < RB; b++)
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            const int dd = d0b + b * NWV, ii = 1 + ln + 64 * h;
+            v[b][h] = (dd <= W - k - 1 && ii <= W - k - dd) ? sv[SV_QM + DOFF(dd) + ii + k - 1] : 0.0;
+          }
+#pragma unroll
+        for (int b = 0; b < RB; b++)
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            const int dd = d0b + b * NWV, ii = 1 + ln + 64 * h;
+            if (dd <= W - k - 1 && ii <= W - k - dd) QMD(dd, ii) = v[b][h];
+          }
+      }
       // derived buffers of the last three old columns (= new columns j0-3 .. j0-1), rows shifted; qm1 of new column j0-1
       for (int x = tid; x < 9 * W; x += SF_PFL_NT) {
         const int kc = x / W, ii = x - kc * W + 1, kind = kc / 3, cn = j0 - 3 + (kc - kind * 3);

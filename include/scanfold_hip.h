@@ -58,7 +58,9 @@ int sf_device_name(char *buf, size_t n); /* e.g. "AMD Instinct MI355X (gfx950), 
 
 /* Folding model.  Replaces RNA.md() + md.temperature (ScanFold-Scan.py:70-71;
  * ScanFoldFunctions.py:776-777): `blob` is a struct sf_params_blob (include/sf_params_blob.h).
- * temperature_c must equal blob->temperature (free energies are not rescaled on the device yet). */
+ * temperature_c must equal blob->temperature (free energies are not rescaled on the device yet).
+ * The library keeps the last TWO distinct sets resident: loading one of them again only switches which one the next launches
+ * use (a scan with -t alternates between the T model of the native folds and the 37 C model of the shuffles). */
 int sf_params_load(const void *blob, size_t nbytes, double temperature_c);
 
 /* md.temperature = T with T != 37 (ScanFold-Scan.py:70-71; ScanFoldFunctions.py:776-777): `blob` holds the free

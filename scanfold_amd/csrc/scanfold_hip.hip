@@ -36,9 +36,25 @@ struct Ctx {
   int n_cu = 0;
   std::string dev_name;
   hipStream_t stream = nullptr;
-  SfDevParams *dP = nullptr;
+  SfDevParams *dP = nullptr;  // the resident model the launches use: one of the two slots below
   SfDevParamsPF *dX = nullptr;
   SfFastParams *dF = nullptr;
+  // Two models stay resident (a scan with -t folds the native windows at T and the shuffles at 37 C, chunk after chunk:
+  // ScanFold-Scan.py:70-71 with F8 of SURVEY.md): loading a set that is already in a slot switches the pointers above, nothing
+  // is rebuilt, copied or waited for.
+  struct ModelSlot {
+    SfDevParams *dP = nullptr;
+    SfDevParamsPF *dX = nullptr;
+    SfFastParams *dF = nullptr;
+    uint64_t key = 0;
+    bool valid = false;
+    int fast_ok = 0;
+    int span = 0;          // the max_bp_span its max_pair_dist field was written for
+    double temperature = 37.0;
+    uint64_t used = 0;     // load counter value of its last use
+  } slot[2];
+  uint64_t loads = 0;
+  int cur = 0;
   double temperature = 37.0;
   DevBuf full_scratch, pf_scratch, pf_share, fast_scratch, seqs, energies, db, cen, dbl, status, transcript, ovf, cons, sc;
   DevBuf tab_in, tab_partner, tab_counts, tab_out;  // sf_tabulate_pairs
@@ -413,9 +429,14 @@ int sf_init(int device_ordinal) {
   g.dev_name = nm;
   g.dev = device_ordinal;
   HIPCHK(hipStreamCreate(&g.stream));
-  HIPCHK(hipMalloc((void **)&g.dP, sizeof(SfDevParams)));
-  HIPCHK(hipMalloc((void **)&g.dX, sizeof(SfDevParamsPF)));
-  HIPCHK(hipMalloc((void **)&g.dF, sizeof(SfFastParams)));
+  for (auto &m : g.slot) {
+    HIPCHK(hipMalloc((void **)&m.dP, sizeof(SfDevParams)));
+    HIPCHK(hipMalloc((void **)&m.dX, sizeof(SfDevParamsPF)));
+    HIPCHK(hipMalloc((void **)&m.dF, sizeof(SfFastParams)));
+    m.valid = false;
+  }
+  g.cur = 0;
+  g.dP = g.slot[0].dP; g.dX = g.slot[0].dX; g.dF = g.slot[0].dF;
   {  // the sticky device status word every traceback ORs into (read and cleared by read_status)
     int rc = ensure(g.status, sizeof(int));
     if (rc) return rc;
@@ -444,9 +465,12 @@ int sf_shutdown(void) {
   }
   for (auto &e : g.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
   g.ev.clear();
-  if (g.dP) hipFree(g.dP);
-  if (g.dX) hipFree(g.dX);
-  if (g.dF) hipFree(g.dF);
+  for (auto &m : g.slot) {
+    if (m.dP) hipFree(m.dP);
+    if (m.dX) hipFree(m.dX);
+    if (m.dF) hipFree(m.dF);
+    m.dP = nullptr; m.dX = nullptr; m.dF = nullptr; m.valid = false;
+  }
   g.dP = nullptr; g.dX = nullptr; g.dF = nullptr;
   if (g.stream) hipStreamDestroy(g.stream);
   g.stream = nullptr;
@@ -480,17 +504,45 @@ int sf_params_load_rescaled(const void *blob, size_t nbytes, double temperature_
     if (P37.magic != SF_PARAMS_MAGIC || P37.version != SF_PARAMS_VERSION) return SF_ERR_BAD_PARAMS;
   }
   if (fabs(P.temperature - temperature_c) > 1e-9) return SF_ERR_TEMPERATURE;
-  static SfDevParams D;
-  static SfDevParamsPF X;
-  static SfFastParams F;
-  build_dev_params(P, D, X, blob_37c ? &P37 : nullptr, blob_37c ? &PdH : nullptr);
-  D.max_pair_dist = g.max_bp_span > 0 ? g.max_bp_span - 1 : 0x7fffffff;
-  sf_fast_build_params(D, F);
-  g.fast_ok = F.fast_ok;
-  HIPCHK(hipDeviceSynchronize());  // *_dev work queued on the callers' own streams still reads the old tables
-  HIPCHK(hipMemcpy(g.dP, &D, sizeof D, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(g.dX, &X, sizeof X, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(g.dF, &F, sizeof F, hipMemcpyHostToDevice));
+  // the set's identity: FNV-1a over the bytes handed in
+  uint64_t key = 1469598103934665603ull;
+  auto mix = [&key](const void *p, size_t n) {
+    const unsigned char *b = (const unsigned char *)p;
+    for (size_t k = 0; k < n; k++) { key ^= b[k]; key *= 1099511628211ull; }
+  };
+  mix(&P, sizeof P);
+  if (blob_37c) { mix(&P37, sizeof P37); mix(&PdH, sizeof PdH); }
+  const int32_t md = g.max_bp_span > 0 ? g.max_bp_span - 1 : 0x7fffffff;
+  g.loads++;
+  int hit = -1;
+  for (int k = 0; k < 2; k++)
+    if (g.slot[k].valid && g.slot[k].key == key) hit = k;
+  if (hit < 0) {
+    // the slot not in use (or the older one) is rebuilt; queued work may still read it
+    const int k = !g.slot[0].valid ? 0 : (!g.slot[1].valid ? 1 : (g.have_params ? 1 - g.cur : (g.slot[0].used <= g.slot[1].used ? 0 : 1)));
+    static SfDevParams D;
+    static SfDevParamsPF X;
+    static SfFastParams F;
+    build_dev_params(P, D, X, blob_37c ? &P37 : nullptr, blob_37c ? &PdH : nullptr);
+    D.max_pair_dist = md;
+    sf_fast_build_params(D, F);
+    HIPCHK(hipDeviceSynchronize());  // *_dev work queued on the callers' own streams may still read that slot's old tables
+    g.slot[k].valid = false;
+    HIPCHK(hipMemcpy(g.slot[k].dP, &D, sizeof D, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(g.slot[k].dX, &X, sizeof X, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(g.slot[k].dF, &F, sizeof F, hipMemcpyHostToDevice));
+    g.slot[k].key = key; g.slot[k].valid = true; g.slot[k].fast_ok = F.fast_ok; g.slot[k].span = g.max_bp_span;
+    g.slot[k].temperature = temperature_c;
+    hit = k;
+  } else if (g.slot[hit].span != g.max_bp_span) {  // sf_set_max_bp_span was called while the other model was the resident one
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy((char *)g.slot[hit].dP + offsetof(SfDevParams, max_pair_dist), &md, sizeof md, hipMemcpyHostToDevice));
+    g.slot[hit].span = g.max_bp_span;
+  }
+  g.slot[hit].used = g.loads;
+  g.cur = hit;
+  g.dP = g.slot[hit].dP; g.dX = g.slot[hit].dX; g.dF = g.slot[hit].dF;
+  g.fast_ok = g.slot[hit].fast_ok;
   g.temperature = temperature_c;
   g.have_params = true;
   return SF_OK;
@@ -861,6 +913,7 @@ int sf_set_max_bp_span(int span) {
     const int32_t md = g.max_bp_span > 0 ? g.max_bp_span - 1 : 0x7fffffff;
     HIPCHK(hipStreamSynchronize(g.stream));
     HIPCHK(hipMemcpy((char *)g.dP + offsetof(SfDevParams, max_pair_dist), &md, sizeof md, hipMemcpyHostToDevice));
+    g.slot[g.cur].span = g.max_bp_span;  // (the other resident model is patched when it is switched to)
   }
   return SF_OK;
 }

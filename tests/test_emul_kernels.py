@@ -214,3 +214,37 @@ def test_max_bp_span_every_kernel(emul, oracle):
         emul.set_kernel_mode(0)
         emul.set_max_bp_span(0)
         oracle.set_max_bp_span(0)
+
+
+def test_two_resident_models_switch_without_reload(emul, oracle):
+    """sf_params_load keeps two models resident (a -t scan alternates between T and 37 C per chunk): going back to a set that is
+    still in a slot must give that set's results again, a third set replaces the one not in use, and a max_bp_span set
+    while the OTHER model was resident applies after the switch."""
+    from par_util import par_text, synthetic_enthalpies
+    base = params.default_params()
+    p = params.parse_par_text(par_text(base.rec, synthetic_enthalpies(base.rec, 3)), source="synthetic.par")
+    rng = np.random.default_rng(8)
+    arr = random_seqs(rng, 4, 60)
+    want = {}
+    try:
+        for t in (37, 25, 50):
+            oracle.set_params(p.at_temperature(t))
+            want[t] = (oracle.mfe_batch(arr), [oracle.pf(bytes(a).decode())["dG"] for a in arr])
+        emul.load_params(p)
+        for t in (37, 25, 37, 25, 50, 25, 37, 50):  # hits, a miss that evicts, then the evicted one again
+            emul.set_temperature(t)
+            assert (emul.mfe_batch(arr) == want[t][0]).all(), t
+            assert np.allclose(emul.pf_batch(arr)["dG"], want[t][1], rtol=0, atol=1e-8), t
+        # span set while 25 C is resident, then back to 37 C (still in its slot)
+        emul.set_temperature(37); emul.set_temperature(25)
+        emul.set_max_bp_span(20); oracle.set_max_bp_span(20)
+        emul.set_temperature(37)
+        oracle.set_params(p.at_temperature(37))
+        assert (emul.mfe_batch(arr) == oracle.mfe_batch(arr)).all()
+        emul.set_temperature(25)
+        oracle.set_params(p.at_temperature(25))
+        assert (emul.mfe_batch(arr) == oracle.mfe_batch(arr)).all()
+    finally:
+        emul.set_max_bp_span(0); oracle.set_max_bp_span(0)
+        oracle.set_params(base)
+        emul.load_params(base)

@@ -67,8 +67,11 @@
 // split steps of the wide kernel (NG = 256, where the split is most of a cell): the helper waves take (terms / 2 - bias)
 // terms of the multiloop split, the ones with the largest m.  The narrow kernel's helpers take none: their special-loop
 // work already balances the main wave (any share measured the same or worse in rounds 2 and 3).
+// (the W = 200 instantiation: 18 / 26 / 34 / 42 / 50 / 60 / 80 -> 142.4 / 140.4 / 138.1 / 136.5 / 135.8 / 136.2 / 137.2 ms per 131 072 folds at
+// the end of round 3; the generic wide instantiation at W = 160: 26 / 42 / 50 / 60 -> 110.6 / 112.0 / 113.1 / 114.2 ms)
 #define SF_DML_HELPER_BIAS_256 26
-#define SF_DML_HELPER_BIAS(ng) ((ng) == 256 ? SF_DML_HELPER_BIAS_256 : 100000)
+#define SF_DML_HELPER_BIAS_W200 50
+#define SF_DML_HELPER_BIAS(ng, wt) ((ng) == 256 ? ((wt) == 200 ? SF_DML_HELPER_BIAS_W200 : SF_DML_HELPER_BIAS_256) : 100000)
 // loop sizes per batch of reads in the bulge / 1xn minima (narrow / wide kernel; measured 2, 3, 4, 6: W=120 best at
 // 3 by 0.6 %, W=200 at 6 by 3.5 %)
 #define SF_HELP_NB_128 3
@@ -1286,7 +1289,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
   // last 62 cells of a diagonal lie in the group's first wave; NG = 256: lane 128, so the last 126 lie in its two
   // middle waves — the other waves of the group then work as helpers (see `split` below).
   constexpr int CENTRE = (NG == 256) ? 128 : 32;
-  constexpr bool SHARE = SF_DML_HELPER_BIAS(NG) < 10000;  // the helper waves take part of the multiloop split
+  constexpr bool SHARE = SF_DML_HELPER_BIAS(NG, WT) < 10000;  // the helper waves take part of the multiloop split
   constexpr bool DML2 = (NG == 128) && SF_FAST_DML2;    // split steps: the main wave splits two cells per lane (sf_fast_dml2)
   const int OFFs = ((W + 1) >> 1) - CENTRE;                  // signed: v = tg + OFFs (mod NG)
   const int OFF = (NG > 64) ? (OFFs + NG) & (NG - 1) : 0;
@@ -1405,7 +1408,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
       // split step: the multiloop split (d-8 terms, the part of a cell that grows with d) is shared with the helper
       // wave: terms m >= dml_cut are the helper's (wave-uniform; both waves of a cell compute the same cut)
       const int dml_terms = d - 2 * SFD_TURN - 2;  // m = 4 .. d-5
-      const int dml_cut = d - SFD_TURN - 1 - sfd_max(sfd_min(dml_terms / 2 - SF_DML_HELPER_BIAS(NG), dml_terms), 0);
+      const int dml_cut = d - SFD_TURN - 1 - sfd_max(sfd_min(dml_terms / 2 - SF_DML_HELPER_BIAS(NG, WT), dml_terms), 0);
       const bool valid = (d < W) && (i >= 1) && (i + d <= W);
       int fpart = SF_FAST_BIG;
       int dec = SF_FAST_BIG, eh = SF_FAST_BIG, e0 = SF_FAST_BIG;

@@ -74,7 +74,7 @@
 #define SF_DML_HELPER_BIAS(ng, wt) ((ng) == 256 ? ((wt) == 200 ? SF_DML_HELPER_BIAS_W200 : SF_DML_HELPER_BIAS_256) : 100000)
 // loop sizes per batch of reads in the bulge / 1xn minima (narrow / wide kernel; measured 2, 3, 4, 6: W=120 best at
 // 3 by 0.6 %, W=200 at 6 by 3.5 %)
-#define SF_HELP_NB_128 3
+#define SF_HELP_NB_128 4
 #define SF_HELP_NB_256 6
 #define SF_INF16 30000
 #define SF_FAST_THRESH 10000
@@ -217,14 +217,19 @@ static inline __host__ __device__ SfFastLayout sf_fast_layout(int W, bool hc = f
   int o = tri * 2;
   const int RW = W - 4;  // a diagonal d >= 4 has at most W-4 cells
   const int roll = ((SF_FAST_NR * RW + 1) & ~1) * 2;
-  L.off_ci = o; o += roll;   // the exterior pass reuses this area for f5[] and the mismatchExt table
+  // (W <= 128: CI has a row NR that mirrors its row 0, so that "the row after row r" exists for every r and the generic-loop
+  // recurrence addresses the rows of two neighbouring loop sizes from ONE per-lane base)
+  // (ring row 0 only ever holds the diagonals NR, 2 NR, ...: at most W - NR cells, so that is all the mirror rows keep)
+  const int mirror = (W <= 128 && W > SF_FAST_NR) ? ((W - SF_FAST_NR + 1) & ~1) : 0;  // entries
+  L.off_ci = o; o += roll + mirror * 2;  // the exterior pass reuses this area for f5[] and the mismatchExt table
   L.off_c1n = o; o += roll;
   L.off_cb = o; o += roll;
   L.off_dml = o;  // (end of the rolling tables; the rolling rows of multiloop-split minima that used to follow are gone)
-  // W < SF_HELP_MERGE_MAXW (merged helper, see the kernel): the interleaved bulge / 1xn table gets row NR = a copy of its row 0, so
-  // that "the row after row r" exists for every r, and each of the two helper waves a 128-byte list of cells
-  // (ring row 0 only ever holds the diagonals NR, 2 NR, ...: at most W - NR cells)
-  if (W < SF_HELP_MERGE_MAXW && SF_HELP_MERGE && W > SF_FAST_NR) o += (W - SF_FAST_NR) * 4;
+  // the interleaved bulge / 1xn table gets row NR = a copy of its row 0 as well ("the row after row r" exists for every r: the
+  // merged helper relies on it too); W < SF_HELP_MERGE_MAXW (merged helper): each of the two helper waves a 128-byte list of cells
+  // (W <= 128: the same mirror row for every narrow instantiation — the bulge / 1xn minima address the rows of two loop sizes
+  // from one base as well)
+  o += mirror * 4;
   L.off_list = o;
   if (W < SF_HELP_MERGE_MAXW && SF_HELP_MERGE) o += 2 * 128;
   // (What follows the rolling tables matters: on the short diagonals the straight-line cell code reads candidates of
@@ -474,7 +479,8 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
 #pragma unroll
       for (int k = 0; k < 3; k++) {
         const int u = 2 * (pb - k) + 4;
-        const int16_t *ra = X.CI + ROW(u) + i0, *rb = X.CI + ROW(u + 1) + i0;
+        // (!FOLD: row u is the row after row u+1 — the mirror row when that is the ring's last — at a compile-time offset)
+        const int16_t *rb = X.CI + ROW(u + 1) + i0, *ra = FOLD ? X.CI + ROW(u) + i0 : rb + RW;
         e1[k] = sf_pk(ra[3], rb[3]);          // u1 = 2
         e2[k] = sf_pk(ra[u - 1], rb[u]);      // u2 = 2
         nn[k] = sf_ldw(uNIN + (u - 4));
@@ -567,7 +573,9 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
           for (int k = 0; k < SF_HELP_NB; k++) {
             const int u = ub + k;
             if (u <= 30) {
-              const int16_t *t = X.BN + 2 * (ROW(u) + i0);
+              // (!FOLD: sizes (u, u+1), u even, share a base — row u is the row after row u+1, the mirror row at the ring's seam)
+              const int16_t *t = (FOLD || u == 30) ? X.BN + 2 * (ROW(u) + i0)
+                                                   : X.BN + 2 * (ROW(u | 1) + i0) + ((u & 1) ? 0 : 2 * RW);
               w0[k] = sf_ldw(t + 2 * 1);
               if (!SHIFT) w1[k] = sf_ldw(t + 2 * 2);
               w2[k] = sf_ldw(t + 2 * (SHIFT ? u - 1 : u)); w3[k] = sf_ldw(t + 2 * (u + 1));
@@ -734,6 +742,7 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
   int f = SF_FAST_BIG, cx = SF_INF16;
   if ((SEC & SF_SEC_POST) && type) {
     X.CI[rbd] = (int16_t)(c + sf_lo(pub.a));
+    if (!FOLD && slotd == 0) X.CI[SF_FAST_NR * RW + i0] = (int16_t)(c + sf_lo(pub.a));
     const uint32_t bn = sf_pk(c + pub.tau, c + sf_hi(pub.a));  // (CB, C1N)
     sf_fast_publish_bn<SHIFT>(X.BN + 2 * rbd, i0, bn);
     if (X.bn_dup && slotd == 0) sf_fast_publish_bn<SHIFT>(X.BN + 2 * (SF_FAST_NR * RW + i0), i0, bn);
@@ -744,6 +753,7 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
     const int sp1 = S[i - 1], sq1 = S[j + 1];
     const int tau_in = tr > 2 ? X.TAU : 0;
     X.CI[rbd] = (int16_t)(c + X.tI[SF_TIDX(tr, sq1, sp1)]);
+    if (!FOLD && slotd == 0) X.CI[SF_FAST_NR * RW + i0] = X.CI[rbd];
     const uint32_t bn = sf_pk(c + tau_in, c + X.t1n[SF_TIDX(tr, sq1, sp1)]);  // (CB, C1N)
     sf_fast_publish_bn<SHIFT>(X.BN + 2 * rbd, i0, bn);
     if (X.bn_dup && slotd == 0) sf_fast_publish_bn<SHIFT>(X.BN + 2 * (SF_FAST_NR * RW + i0), i0, bn);
@@ -758,6 +768,7 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
     cx = sfd_min(c + ext + tau_in, SF_INF16);
   } else {
     X.CI[rbd] = SF_INF16; sf_fast_publish_bn<SHIFT>(X.BN + 2 * rbd, i0, sf_pk(SF_INF16, SF_INF16));
+    if (!FOLD && slotd == 0) X.CI[SF_FAST_NR * RW + i0] = SF_INF16;
     if (X.bn_dup && slotd == 0) sf_fast_publish_bn<SHIFT>(X.BN + 2 * (SF_FAST_NR * RW + i0), i0, sf_pk(SF_INF16, SF_INF16));
   }
   // the scratch (row i, column j: the exterior sweep reads rows coalesced) takes c + ExtLoop, the only form the
@@ -1253,7 +1264,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
   X.S = S;
   X.D = D; X.F = F; X.W = W; X.fold = FOLD; X.maxd = D->max_pair_dist;
   constexpr bool MERGE = MG && SF_HELP_MERGE && (NG == 128);
-  X.bn_dup = MERGE;
+  X.bn_dup = (NG == 128);
   uint8_t *const cell_list = (uint8_t *)(smem + Lo.off_list);
   X.TAU = D->P.TerminalAU; X.MLbase = D->P.MLbase; X.MLclosing = D->P.MLclosing; X.MLintern = D->P.MLintern[1];
   // exterior pass aliases (the rolling CI area is dead by then)

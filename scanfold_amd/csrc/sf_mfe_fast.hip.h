@@ -503,6 +503,19 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
   // ---- special loops, bulges, 1 x n loops (pairable cells): eh ----
   if (SEC & SF_SEC_HELP) {
     eh = SF_FAST_BIG;
+    // The lane's byte offset into a row of the interleaved table, pinned: a row's address is then ONE add of the row's scalar
+    // byte offset (the compiler otherwise rebuilds (row + lane) * 4 + table base — three vector instructions — for every row,
+    // because the two-word reads have no room for the base in their offset fields).
+#ifdef SF_EMUL
+    const int bno = 4 * i0;
+#define BNROW(r) ((const int16_t *)((const char *)X.BN + (bno + 4 * (r))))
+#else
+    // (the table's own LDS offset goes into the pinned value too — the low half of a flat LDS address is the LDS offset — so
+    // that nothing but the row's scalar offset is left to add)
+    unsigned bno = (unsigned)(uintptr_t)(const void *)X.BN + 4u * (unsigned)i0;
+    if (!G) SF_PIN(bno);
+#define BNROW(r) ((const int16_t *)(const __attribute__((address_space(3))) int16_t *)(uintptr_t)(bno + 4u * (unsigned)(r)))
+#endif
     if (type && (!G || umax >= 0)) {
       const int TAU = X.TAU;
       const int tau_out = type > 2 ? TAU : 0;
@@ -513,11 +526,11 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
       {  // stack (+ the Deigan pseudo-energies of its four nucleotides: fc.sc_add_SHAPE_deigan, ScanFold.py:533-539)
         const int t2r = RP[si1 * 8 + sj1];
         const int sc4 = X.sc ? X.sc[i] + X.sc[i + 1] + X.sc[j - 1] + X.sc[j] : 0;
-        eh = sfd_min(eh, CBAT(ROW(0) + i0 + 1) + st[t2r] + sc4);
+        eh = sfd_min(eh, BNROW(ROW(0))[2 * 1] + st[t2r] + sc4);
       }
       if (!G || umax >= 1) {  // one-nucleotide bulges keep the stack
         const int b1 = SF_UNI(uBN, 2);
-        const int16_t *row = X.BN + 2 * (ROW(1) + i0);
+        const int16_t *row = BNROW(ROW(1));
         const int ta = RP[si1 * 8 + S[j - 2]];  // (i+1, j-2)
         eh = sfd_min(eh, row[2 * 1] + b1 + st[ta]);
         const int tb = RP[S[i + 2] * 8 + sj1];  // (i+2, j-1)
@@ -525,10 +538,10 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
       }
       if (!G || (UCAP >= 2 && umax >= 2)) {  // 1 x 1: (i+2, j-2)
         const unsigned t2r = RP[S[i + 2] * 8 + S[j - 2]];
-        eh = sfd_min(eh, CBAT(ROW(2) + i0 + 2) + Fc->int11T[((tq + t2r) * 5u + si1) * 5u + sj1]);
+        eh = sfd_min(eh, BNROW(ROW(2))[2 * 2] + Fc->int11T[((tq + t2r) * 5u + si1) * 5u + sj1]);
       }
       if (!G || (UCAP >= 3 && umax >= 3)) {  // 1 x 2 and 2 x 1
-        const int16_t *row = X.BN + 2 * (ROW(3) + i0);
+        const int16_t *row = BNROW(ROW(3));
         const unsigned ta = RP[S[i + 2] * 8 + S[j - 3]];  // (i+2, j-3), sq1 = S[j-2]
         eh = sfd_min(eh, row[2 * 2] + Fc->int21a[(((tq + ta) * 5u + si1) * 5u + S[j - 2]) * 5u + sj1]);
         const unsigned tb = RP[S[i + 3] * 8 + S[j - 2]];  // (i+3, j-2), sp1 = S[i+2]
@@ -536,11 +549,11 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
       }
       if (!G || (UCAP >= 4 && umax >= 4)) {  // 2 x 2: (i+3, j-3)
         const unsigned t2r = RP[S[i + 3] * 8 + S[j - 3]];
-        eh = sfd_min(eh, CBAT(ROW(4) + i0 + 3) +
+        eh = sfd_min(eh, BNROW(ROW(4))[2 * 3] +
                              Fc->int22T[((((tq + t2r) * 5u + si1) * 5u + S[i + 2]) * 5u + S[j - 2]) * 5u + sj1]);
       }
       if (!G || (UCAP >= 5 && umax >= 5)) {  // 2 x 3 and 3 x 2
-        const int16_t *row = X.BN + 2 * (ROW(5) + i0);
+        const int16_t *row = BNROW(ROW(5));
         const int m23 = X.t23[SF_TIDX(type, si1, sj1)] + Fc->L23;
         const int ta = RP[S[i + 3] * 8 + S[j - 4]];  // (i+3, j-4); sp1 = S[i+2], sq1 = S[j-3]
         eh = sfd_min(eh, row[2 * 3] + m23 + X.t23in[SF_TIDX(ta, S[j - 3], S[i + 2])]);
@@ -574,8 +587,7 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
             const int u = ub + k;
             if (u <= 30) {
               // (!FOLD: sizes (u, u+1), u even, share a base — row u is the row after row u+1, the mirror row at the ring's seam)
-              const int16_t *t = (FOLD || u == 30) ? X.BN + 2 * (ROW(u) + i0)
-                                                   : X.BN + 2 * (ROW(u | 1) + i0) + ((u & 1) ? 0 : 2 * RW);
+              const int16_t *t = (FOLD || u == 30) ? BNROW(ROW(u)) : BNROW(ROW(u | 1)) + ((u & 1) ? 0 : 2 * RW);
               w0[k] = sf_ldw(t + 2 * 1);
               if (!SHIFT) w1[k] = sf_ldw(t + 2 * 2);
               w2[k] = sf_ldw(t + 2 * (SHIFT ? u - 1 : u)); w3[k] = sf_ldw(t + 2 * (u + 1));
@@ -787,6 +799,7 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
   // final on the even diagonal; provisional (neighbour term still missing) on the odd one
   X.fML[FBASE(d) + i0] = (int16_t)(f > SF_FAST_THRESH ? SF_INF16 : f);
 #undef ROW
+#undef BNROW
 }
 
 // minimum over the 64 lanes of a wave, returned in every lane.  DPP row operations + one readlane: no LDS

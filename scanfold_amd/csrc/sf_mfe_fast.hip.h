@@ -9,7 +9,7 @@
 // thread two diagonals later is (i-1, j+1), the cell that encloses it — which makes the interior-loop search
 // incremental (below) with all of its state in registers.
 //
-// LDS per workgroup (W=120: 40.4 kB -> 4 workgroups per CU):
+// LDS per workgroup (W=120: 40.9 kB -> 4 workgroups per CU):
 //   fML   int16, every diagonal (the O(W^3) multiloop split reads them all).  W <= 128: a triangle, diagonal after
 //         diagonal, each starting at an even index (two neighbouring cells = one aligned word: sf_fast_dml2).  W > 128 (FOLD): folded into a rectangle — diagonal x <= H = (W+3)/2 is the left part of row x-4,
 //         diagonal W+3-x the right part of the same row (their lengths add up to the row length W-3) — so that a

@@ -71,74 +71,78 @@ __global__ __launch_bounds__(NT) void sf_pf_fast_kernel(const uint8_t *__restric
     // GT = std::true_type: loop sizes are tested against the limit d-6.  (A false_type instantiation makes the
     // candidate code straight-line; in FP64 that needs >256 VGPRs and spills, so it is not used.)
     auto inside_step = [&](const int d, double(&H)[27], auto GT) {
+      // (parameter blocks through sf_const_base: their tables addressed "one scalar base + offset" — the compiler otherwise keeps
+      // one hoisted 64-bit address per table row in scalar registers it does not have: thousands of v_readlane restores)
+      const SfDevParamsPF *const Xc = sf_const_base(X);
+      const SfDevParams *const Dc = sf_const_base(D);
       constexpr bool G = decltype(GT)::value;
       const int i = v - (d >> 1), j = i + d;
       const bool valid = (i >= 1) && (j <= W);
       if (valid) {
         const int umax = G ? sfd_min(SFD_MAXLOOP, d - 2 - (SFD_TURN + 1)) : SFD_MAXLOOP;
-        const int type = j - i <= D->max_pair_dist ? D->pair[S[i]][S[j]] : 0;
+        const int type = j - i <= Dc->max_pair_dist ? Dc->pair[S[i]][S[j]] : 0;
         const int si1 = S[i + 1], sj1 = S[j - 1];
         // generic interior sums of this cell from those of the enclosed cell
 #pragma unroll
         for (int u = 30; u >= 6; --u)
-          if (!G || u <= umax) H[u - 4] = H[u - 6] + (PT(T.QBI, d - 2 - u, i + 3) + PT(T.QBI, d - 2 - u, i + u - 1)) * X->ninio[u - 4];
-        if (!G || umax >= 5) H[1] = (PT(T.QBI, d - 7, i + 3) + PT(T.QBI, d - 7, i + 4)) * X->ninio[1];
-        if (!G || umax >= 4) H[0] = PT(T.QBI, d - 6, i + 3) * X->ninio[0];
+          if (!G || u <= umax) H[u - 4] = H[u - 6] + (PT(T.QBI, d - 2 - u, i + 3) + PT(T.QBI, d - 2 - u, i + u - 1)) * Xc->ninio[u - 4];
+        if (!G || umax >= 5) H[1] = (PT(T.QBI, d - 7, i + 3) + PT(T.QBI, d - 7, i + 4)) * Xc->ninio[1];
+        if (!G || umax >= 4) H[0] = PT(T.QBI, d - 6, i + 3) * Xc->ninio[0];
         double qbij = 0.0;
         if (type) {
-          double z = sfx_hairpin(D, X, S, i, j, type);
+          double z = sfx_hairpin(Dc, Xc, S, i, j, type);
           if (!G || umax >= 0) {
             const double tau_out = type > 2 ? xTAU : 1.0;
-            z += PT(T.QB, d - 2, i + 1) * X->stack[type][sfd_rtype(D->pair[si1][sj1])];
+            z += PT(T.QB, d - 2, i + 1) * Xc->stack[type][sfd_rtype(Dc->pair[si1][sj1])];
             if (!G || umax >= 1) {
-              const int ta = sfd_rtype(D->pair[si1][S[j - 2]]), tb = sfd_rtype(D->pair[S[i + 2]][sj1]);
-              z += (PT(T.QB, d - 3, i + 1) * X->stack[type][ta] + PT(T.QB, d - 3, i + 2) * X->stack[type][tb]) * X->bulge[1];
+              const int ta = sfd_rtype(Dc->pair[si1][S[j - 2]]), tb = sfd_rtype(Dc->pair[S[i + 2]][sj1]);
+              z += (PT(T.QB, d - 3, i + 1) * Xc->stack[type][ta] + PT(T.QB, d - 3, i + 2) * Xc->stack[type][tb]) * Xc->bulge[1];
             }
             if (!G || umax >= 2) {
-              const int t2r = sfd_rtype(D->pair[S[i + 2]][S[j - 2]]);
-              z += PT(T.QB, d - 4, i + 2) * X->int11[type][t2r][si1][sj1];
+              const int t2r = sfd_rtype(Dc->pair[S[i + 2]][S[j - 2]]);
+              z += PT(T.QB, d - 4, i + 2) * Xc->int11[type][t2r][si1][sj1];
             }
             if (!G || umax >= 3) {
-              const int ta = sfd_rtype(D->pair[S[i + 2]][S[j - 3]]), tb = sfd_rtype(D->pair[S[i + 3]][S[j - 2]]);
-              z += PT(T.QB, d - 5, i + 2) * X->int21[type][ta][si1][S[j - 2]][sj1] +
-                   PT(T.QB, d - 5, i + 3) * X->int21[tb][type][sj1][si1][S[i + 2]];
+              const int ta = sfd_rtype(Dc->pair[S[i + 2]][S[j - 3]]), tb = sfd_rtype(Dc->pair[S[i + 3]][S[j - 2]]);
+              z += PT(T.QB, d - 5, i + 2) * Xc->int21[type][ta][si1][S[j - 2]][sj1] +
+                   PT(T.QB, d - 5, i + 3) * Xc->int21[tb][type][sj1][si1][S[i + 2]];
             }
             if (!G || umax >= 4) {
-              const int t2r = sfd_rtype(D->pair[S[i + 3]][S[j - 3]]);
-              z += PT(T.QB, d - 6, i + 3) * X->int22[type][t2r][si1][S[i + 2]][S[j - 2]][sj1];
+              const int t2r = sfd_rtype(Dc->pair[S[i + 3]][S[j - 3]]);
+              z += PT(T.QB, d - 6, i + 3) * Xc->int22[type][t2r][si1][S[i + 2]][S[j - 2]][sj1];
             }
             if (!G || umax >= 5) {
-              const int ta = sfd_rtype(D->pair[S[i + 3]][S[j - 4]]), tb = sfd_rtype(D->pair[S[i + 4]][S[j - 3]]);
-              const double m23 = X->internal_loop[5] * X->ninio[1] * X->mismatch23I[type][si1][sj1];
-              z += m23 * (PT(T.QB, d - 7, i + 3) * X->mismatch23I[ta][S[j - 3]][S[i + 2]] +
-                          PT(T.QB, d - 7, i + 4) * X->mismatch23I[tb][S[j - 2]][S[i + 3]]);
+              const int ta = sfd_rtype(Dc->pair[S[i + 3]][S[j - 4]]), tb = sfd_rtype(Dc->pair[S[i + 4]][S[j - 3]]);
+              const double m23 = Xc->internal_loop[5] * Xc->ninio[1] * Xc->mismatch23I[type][si1][sj1];
+              z += m23 * (PT(T.QB, d - 7, i + 3) * Xc->mismatch23I[ta][S[j - 3]][S[i + 2]] +
+                          PT(T.QB, d - 7, i + 4) * Xc->mismatch23I[tb][S[j - 2]][S[i + 3]]);
             }
             double gb = 0.0, g1 = 0.0, gg = 0.0;
 #pragma unroll
             for (int u = 2; u <= 30; ++u)
               if (!G || u <= umax) {
-                gb += (PT(T.QBB, d - 2 - u, i + 1) + PT(T.QBB, d - 2 - u, i + 1 + u)) * X->bulge[u];
+                gb += (PT(T.QBB, d - 2 - u, i + 1) + PT(T.QBB, d - 2 - u, i + 1 + u)) * Xc->bulge[u];
                 if (u >= 4)
-                  g1 += (PT(T.QB1N, d - 2 - u, i + 2) + PT(T.QB1N, d - 2 - u, i + u)) * X->internal_loop[u] * X->ninio[u - 2];
-                if (u >= 6) gg += H[u - 4] * X->internal_loop[u];
+                  g1 += (PT(T.QB1N, d - 2 - u, i + 2) + PT(T.QB1N, d - 2 - u, i + u)) * Xc->internal_loop[u] * Xc->ninio[u - 2];
+                if (u >= 6) gg += H[u - 4] * Xc->internal_loop[u];
               }
-            z += gb * tau_out + g1 * X->mismatch1nI[type][si1][sj1] + gg * X->mismatchI[type][si1][sj1];
+            z += gb * tau_out + g1 * Xc->mismatch1nI[type][si1][sj1] + gg * Xc->mismatchI[type][si1][sj1];
           }
           double ml = 0.0;
 #pragma unroll 4
           for (int a = SFD_TURN + 2; a <= d - SFD_TURN - 2; a++) ml += PT(T.QM, a - 2, i + 1) * PT(T.QM1, d - 1 - a, i + a);
-          z += ml * X->MLclosing * sfx_mlstem(X, sfd_rtype(type), sj1, si1);
+          z += ml * Xc->MLclosing * sfx_mlstem(Xc, sfd_rtype(type), sj1, si1);
           qbij = z;
         }
         {
           const int tr = sfd_rtype(type);
           const int sp1 = S[i - 1], sq1 = S[j + 1];
           PT(T.QB, d, i) = qbij;
-          PT(T.QBI, d, i) = type ? qbij * X->mismatchI[tr][sq1][sp1] : 0.0;
-          PT(T.QB1N, d, i) = type ? qbij * X->mismatch1nI[tr][sq1][sp1] : 0.0;
+          PT(T.QBI, d, i) = type ? qbij * Xc->mismatchI[tr][sq1][sp1] : 0.0;
+          PT(T.QB1N, d, i) = type ? qbij * Xc->mismatch1nI[tr][sq1][sp1] : 0.0;
           PT(T.QBB, d, i) = (type && tr > 2) ? qbij * xTAU : qbij;
-          double m1 = PT(T.QM1, d - 1, i) * X->MLbase;
-          if (type) m1 += qbij * sfx_mlstem(X, type, i > 1 ? sp1 : -1, j < W ? sq1 : -1);
+          double m1 = PT(T.QM1, d - 1, i) * Xc->MLbase;
+          if (type) m1 += qbij * sfx_mlstem(Xc, type, i > 1 ? sp1 : -1, j < W ? sq1 : -1);
           PT(T.QM1, d, i) = m1;
           double m = m1;
 #pragma unroll 4
@@ -190,6 +194,10 @@ __global__ __launch_bounds__(NT) void sf_pf_fast_kernel(const uint8_t *__restric
     for (int u = 0; u < 27; u++) { Ha[u] = 0.0; Hb[u] = 0.0; }
     double mbd = 0.0, cd = 0.0;
     auto outside_step = [&](const int d, double(&G)[27], auto GT) {
+      // (parameter blocks through sf_const_base: their tables addressed "one scalar base + offset" — the compiler otherwise keeps
+      // one hoisted 64-bit address per table row in scalar registers it does not have: thousands of v_readlane restores)
+      const SfDevParamsPF *const Xc = sf_const_base(X);
+      const SfDevParams *const Dc = sf_const_base(D);
       constexpr bool GU = decltype(GT)::value;  // true: some enclosing diagonals d+2+u fall outside the table
       const int i = v - (d >> 1), j = i + d;
       const bool valid = (i >= 1) && (j <= W);
@@ -207,21 +215,21 @@ __global__ __launch_bounds__(NT) void sf_pf_fast_kernel(const uint8_t *__restric
               const int dd = d + 2 + u;
               const double e1 = (i - 3 >= 1 && j + u - 1 <= W) ? PT(T.OBI, dd, i - 3) : 0.0;      // u1 = 2
               const double e2 = (i - u + 1 >= 1 && j + 3 <= W) ? PT(T.OBI, dd, i - u + 1) : 0.0;  // u2 = 2
-              G[u - 4] = G[u - 6] + (e1 + e2) * X->ninio[u - 4];
+              G[u - 4] = G[u - 6] + (e1 + e2) * Xc->ninio[u - 4];
             } else {
               G[u - 4] = 0.0;
             }
           if (!GU || uomax >= 5) {
             const double e1 = (i - 3 >= 1 && j + 4 <= W) ? PT(T.OBI, d + 7, i - 3) : 0.0;
             const double e2 = (i - 4 >= 1 && j + 3 <= W) ? PT(T.OBI, d + 7, i - 4) : 0.0;
-            G[1] = (e1 + e2) * X->ninio[1];
+            G[1] = (e1 + e2) * Xc->ninio[1];
           } else G[1] = 0.0;
-          G[0] = ((!GU || uomax >= 4) && i - 3 >= 1 && j + 3 <= W) ? PT(T.OBI, d + 6, i - 3) * X->ninio[0] : 0.0;
+          G[0] = ((!GU || uomax >= 4) && i - 3 >= 1 && j + 3 <= W) ? PT(T.OBI, d + 6, i - 3) * Xc->ninio[0] : 0.0;
         }
         // helper tables for multiloops closed by (k, j), k < i: indexed by the closer's span dd = j - k
         double a0 = 0.0, a1 = 0.0;
         if (i > 1) {
-          a0 = PT(T.A0, d + 1, i - 1) * X->MLbase + PT(T.OBW, d + 1, i - 1);
+          a0 = PT(T.A0, d + 1, i - 1) * Xc->MLbase + PT(T.OBW, d + 1, i - 1);
           {
             // closers (kk, j) with kk = j - dd >= 1: a per-thread bound, no test inside the loop
             const int ddmax = sfd_min(W - 1, j - 1);
@@ -238,45 +246,45 @@ __global__ __launch_bounds__(NT) void sf_pf_fast_kernel(const uint8_t *__restric
         }
         PT(T.A0, d, i) = a0;
         PT(T.A1, d, i) = a1;
-        const int type = j - i <= D->max_pair_dist ? D->pair[S[i]][S[j]] : 0;
+        const int type = j - i <= Dc->max_pair_dist ? Dc->pair[S[i]][S[j]] : 0;
         const double qbij = PT(T.QB, d, i);
         double o = 0.0;
         if (type && qbij != 0.0) {
-          o = q5[i - 1] * q3[j + 1] * sfx_extloop(X, type, i > 1 ? S[i - 1] : -1, j < W ? S[j + 1] : -1);
+          o = q5[i - 1] * q3[j + 1] * sfx_extloop(Xc, type, i > 1 ? S[i - 1] : -1, j < W ? S[j + 1] : -1);
           if (inner) {
             const int rt = sfd_rtype(type);
             const int sp1 = S[i - 1], sq1 = S[j + 1];
             // special loops; (kk,l) is the enclosing pair, its type tk, its inner neighbours S[kk+1], S[l-1]
 #define OBV(kk, l) (((kk) >= 1 && (l) <= W) ? PT(T.OB, (l) - (kk), (kk)) : 0.0)
-#define TK(kk, l) (((kk) >= 1 && (l) <= W) ? D->pair[S[kk]][S[l]] : 0)
+#define TK(kk, l) (((kk) >= 1 && (l) <= W) ? Dc->pair[S[kk]][S[l]] : 0)
 #define SS(x) S[(x) < 0 ? 0 : ((x) > W + 1 ? W + 1 : (x))]  /* neighbours of pairs that may not exist */
             {
               const int tk = TK(i - 1, j + 1);
-              o += OBV(i - 1, j + 1) * X->stack[tk][rt];
+              o += OBV(i - 1, j + 1) * Xc->stack[tk][rt];
             }
             {
               const int ta = TK(i - 1, j + 2), tb = TK(i - 2, j + 1);
-              o += (OBV(i - 1, j + 2) * X->stack[ta][rt] + OBV(i - 2, j + 1) * X->stack[tb][rt]) * X->bulge[1];
+              o += (OBV(i - 1, j + 2) * Xc->stack[ta][rt] + OBV(i - 2, j + 1) * Xc->stack[tb][rt]) * Xc->bulge[1];
             }
             {
               const int tk = TK(i - 2, j + 2);
-              o += OBV(i - 2, j + 2) * X->int11[tk][rt][S[i - 1]][S[j + 1]];
+              o += OBV(i - 2, j + 2) * Xc->int11[tk][rt][S[i - 1]][S[j + 1]];
             }
             {
               const int ta = TK(i - 2, j + 3);  // u1 = 1, u2 = 2
-              o += OBV(i - 2, j + 3) * X->int21[ta][rt][S[i - 1]][sq1][SS(j + 2)];
+              o += OBV(i - 2, j + 3) * Xc->int21[ta][rt][S[i - 1]][sq1][SS(j + 2)];
               const int tb = TK(i - 3, j + 2);  // u1 = 2, u2 = 1
-              o += OBV(i - 3, j + 2) * X->int21[rt][tb][sq1][SS(i - 2)][sp1];
+              o += OBV(i - 3, j + 2) * Xc->int21[rt][tb][sq1][SS(i - 2)][sp1];
             }
             {
               const int tk = TK(i - 3, j + 3);
-              o += OBV(i - 3, j + 3) * X->int22[tk][rt][SS(i - 2)][sp1][sq1][SS(j + 2)];
+              o += OBV(i - 3, j + 3) * Xc->int22[tk][rt][SS(i - 2)][sp1][sq1][SS(j + 2)];
             }
             {
-              const double m23 = X->internal_loop[5] * X->ninio[1] * X->mismatch23I[rt][sq1][sp1];
+              const double m23 = Xc->internal_loop[5] * Xc->ninio[1] * Xc->mismatch23I[rt][sq1][sp1];
               const int ta = TK(i - 3, j + 4), tb = TK(i - 4, j + 3);
-              o += m23 * (OBV(i - 3, j + 4) * X->mismatch23I[ta][SS(i - 2)][SS(j + 3)] +
-                          OBV(i - 4, j + 3) * X->mismatch23I[tb][SS(i - 3)][SS(j + 2)]);
+              o += m23 * (OBV(i - 3, j + 4) * Xc->mismatch23I[ta][SS(i - 2)][SS(j + 3)] +
+                          OBV(i - 4, j + 3) * Xc->mismatch23I[tb][SS(i - 3)][SS(j + 2)]);
             }
 #undef OBV
 #undef TK
@@ -288,15 +296,15 @@ __global__ __launch_bounds__(NT) void sf_pf_fast_kernel(const uint8_t *__restric
                 const int dd = d + 2 + u;
                 const double b1 = (j + 1 + u <= W) ? PT(T.OBB, dd, i - 1) : 0.0;          // u1 = 0
                 const double b2 = (i - 1 - u >= 1) ? PT(T.OBB, dd, i - 1 - u) : 0.0;      // u2 = 0
-                gb += (b1 + b2) * X->bulge[u];
+                gb += (b1 + b2) * Xc->bulge[u];
                 if (u >= 4) {
                   const double n1 = (i - 2 >= 1 && j + u <= W) ? PT(T.OB1N, dd, i - 2) : 0.0;  // u1 = 1
                   const double n2 = (i - u >= 1 && j + 2 <= W) ? PT(T.OB1N, dd, i - u) : 0.0;  // u2 = 1
-                  g1 += (n1 + n2) * X->internal_loop[u] * X->ninio[u - 2];
+                  g1 += (n1 + n2) * Xc->internal_loop[u] * Xc->ninio[u - 2];
                 }
-                if (u >= 6) gg += G[u - 4] * X->internal_loop[u];
+                if (u >= 6) gg += G[u - 4] * Xc->internal_loop[u];
               }
-            o += gb * (rt > 2 ? xTAU : 1.0) + g1 * X->mismatch1nI[rt][sq1][sp1] + gg * X->mismatchI[rt][sq1][sp1];
+            o += gb * (rt > 2 ? xTAU : 1.0) + g1 * Xc->mismatch1nI[rt][sq1][sp1] + gg * Xc->mismatchI[rt][sq1][sp1];
             // (i,j) as a stem of a multiloop closed by (k,l): indexed by the span dd = l - i
             double mlsum = 0.0;
             {
@@ -317,16 +325,16 @@ __global__ __launch_bounds__(NT) void sf_pf_fast_kernel(const uint8_t *__restric
               }
               mlsum += ms2;
             }
-            o += mlsum * sfx_mlstem(X, type, sp1, sq1);
+            o += mlsum * sfx_mlstem(Xc, type, sp1, sq1);
           }
         }
         {
           const int si1 = S[i + 1], sj1 = S[j - 1];
           PT(T.OB, d, i) = o;
-          PT(T.OBI, d, i) = type ? o * X->mismatchI[type][si1][sj1] : 0.0;
-          PT(T.OB1N, d, i) = type ? o * X->mismatch1nI[type][si1][sj1] : 0.0;
+          PT(T.OBI, d, i) = type ? o * Xc->mismatchI[type][si1][sj1] : 0.0;
+          PT(T.OB1N, d, i) = type ? o * Xc->mismatch1nI[type][si1][sj1] : 0.0;
           PT(T.OBB, d, i) = (type > 2) ? o * xTAU : o;
-          PT(T.OBW, d, i) = type ? o * X->MLclosing * sfx_mlstem(X, sfd_rtype(type), sj1, si1) : 0.0;
+          PT(T.OBW, d, i) = type ? o * Xc->MLclosing * sfx_mlstem(Xc, sfd_rtype(type), sj1, si1) : 0.0;
           const double p = o * qbij / Z;
           mbd += p * (1.0 - p);
           if (p > 0.5) {

@@ -26,7 +26,7 @@ struct SfPfTabs {
 };
 
 template <int NT, int WT>
-__global__ __launch_bounds__(NT) void sf_pf_fast_kernel(const uint8_t *__restrict__ seqs, int n, int row_stride, int Wrt,
+__global__ __launch_bounds__(NT, 2) void sf_pf_fast_kernel(const uint8_t *__restrict__ seqs, int n, int row_stride, int Wrt,
                                                         const SfDevParams *__restrict__ D,
                                                         const SfDevParamsPF *__restrict__ X,
                                                         double *__restrict__ scratch, double *__restrict__ ens_dG,

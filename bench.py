@@ -32,23 +32,44 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 WORKLOADS = {
+    # BASELINE.json configs[0] / configs[1]: the small parity shapes — here so that the bench's own path (device-resident
+    # scan, record packing, the RCCL gather, the self-check) can run in seconds inside the GPU test suite
+    "cfg1": dict(name="cfg1: 1 kb synthetic RNA, W=120, step=40, 10 di-shuffles", L=1000, seed=1, W=120, step=40, r=10,
+                 shuffle="di", shuffle_seed=2026, metric="windows/sec (W=120, step=40, 10 shuffles)", verify=23,
+                 counters="profiles/r04/mfe_counters.json"),
+    "cfg2": dict(name="cfg2: 10 kb synthetic RNA, W=120, step=10, 30 di-shuffles", L=10000, seed=2, W=120, step=10, r=30,
+                 shuffle="di", shuffle_seed=2026, metric="windows/sec (W=120, step=10, 30 shuffles)", verify=64,
+                 counters="profiles/r04/mfe_counters.json"),
     # BASELINE.json configs[2] — the configuration the metric is quoted on; the default
     "cfg3": dict(name="cfg3: 30 kb synthetic RNA, W=120, step=1, 100 di-shuffles", L=30000, seed=3, W=120, step=1, r=100,
                  shuffle="di", shuffle_seed=2026, metric="windows/sec (W=120, step=1, 100 shuffles)", verify=64,
-                 counters="profiles/r03/mfe_counters.json"),
+                 counters="profiles/r04/mfe_counters.json"),
     # BASELINE.json configs[4] on the GPUs given (`--config cfg5`; one step is ~36 s on one MI355X)
     "cfg5": dict(name="cfg5: 30 kb synthetic RNA, W=200, step=1, 1000 di-shuffles + partition function", L=30000, seed=3,
                  W=200, step=1, r=1000, shuffle="di", shuffle_seed=2026,
                  metric="windows/sec (W=200, step=1, 1000 shuffles, partition function)", verify=4,
-                 counters="profiles/r03/cfg5_mfe_counters.json"),
+                 counters="profiles/r04/cfg5_mfe_counters.json"),
 }
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 EXIT_NEED_GPUS = 3
 
 
-def synth_transcript(L, seed):
+def synth_transcript(L, seed, kind="uniform"):
+    """uniform: i.i.d. over ACGU (SURVEY.md 8d's generator).  viral: 8d's secondary input — 60 % A+U background with
+    an 80-nt hairpin (38-bp GC-rich stem, GAAA loop) planted every 5 kb, so that some native windows are much more
+    stable than their shuffles (z-scores far from 0) — the workload shape a real scan has."""
     import numpy as np
-    return "".join("ACGU"[k] for k in np.random.default_rng(seed).integers(0, 4, L))
+    rng = np.random.default_rng(seed)
+    if kind == "uniform":
+        return "".join("ACGU"[k] for k in rng.integers(0, 4, L))
+    if kind != "viral":
+        raise ValueError("input kind must be 'uniform' or 'viral'")
+    bg = ["ACGU"[k] for k in rng.choice(4, L, p=[0.3, 0.2, 0.2, 0.3])]
+    comp = str.maketrans("ACGU", "UGCA")
+    for pos in range(1000, L - 100, 5000):
+        stem = "".join("ACGU"[k] for k in rng.choice(4, 38, p=[0.15, 0.35, 0.35, 0.15]))
+        bg[pos:pos + 80] = list(stem + "GAAA" + stem[::-1].translate(comp))
+    return "".join(bg)
 
 
 def relaunch_under_torchrun(args):
@@ -61,7 +82,7 @@ def relaunch_under_torchrun(args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__),
            "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup)]
-    cmd += ["--config", args.config]
+    cmd += ["--config", args.config, "--shuffle", args.shuffle or "", "--input", args.input]
     if args.no_live_counters:
         cmd.append("--no-live-counters")
     if args.no_cpu_baseline:
@@ -165,10 +186,12 @@ def _noop(x):
     return x
 
 
-def live_counters_per_fold(W, groups, n_folds=131072, timeout_s=60):
-    """Hardware counters of the dominant kernel per fold, measured NOW: one `rocprofv3 --pmc <group>` pass per group
-    (separate runs, as MI355X_MICROARCH.md prescribes) of tools/gpu_mfe_only.py as CHILD processes (this process keeps the
-    GPU; it is idle meanwhile).  -> ({counter: value per fold}, None) or (None, why not)."""
+def live_counters_per_fold(config, shuffle, input_kind, groups, windows=0, timeout_s=240):
+    """Hardware counters of the dominant kernel per fold, measured NOW on the workload that was just timed: one
+    `rocprofv3 --pmc <group>` pass per group (separate runs, as MI355X_MICROARCH.md prescribes) of tools/gpu_scan_only.py —
+    ONE scan of the same transcript with the same shuffles, no warm-up launch — as CHILD processes (this process keeps the
+    GPU; it is idle meanwhile).  Every sf_mfe_fast_kernel dispatch of the child belongs to the step, so the sums are the
+    step's.  -> ({counter: value per fold, "_folds": n, "_launches": n}, None) or (None, why not)."""
     import csv
     import glob
     import shutil
@@ -176,32 +199,75 @@ def live_counters_per_fold(W, groups, n_folds=131072, timeout_s=60):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
-    tool = os.path.join(ROOT, "tools", "gpu_mfe_only.py")
-    vals = {}
+    tool = os.path.join(ROOT, "tools", "gpu_scan_only.py")
+    targs = [config, "--input", input_kind] + (["--shuffle", shuffle] if shuffle else []) + (["--windows", str(windows)] if windows else [])
+    vals, folds, launches = {}, None, None
     tmp = tempfile.mkdtemp(prefix="sf_pmc_", dir="/tmp")
     try:
         for k, group in enumerate(groups):
             out = os.path.join(tmp, "g%d" % k)
             try:
                 p = subprocess.run([exe, "--pmc"] + group.split() + ["--kernel-trace", "--output-format", "csv", "-d", out, "--",
-                                    sys.executable, tool, str(n_folds), str(W)], cwd="/tmp",
-                                   env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
+                                    sys.executable, tool] + targs, cwd="/tmp",
+                                   env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                                    text=True, timeout=timeout_s)
             except Exception as e:
                 return None, "rocprofv3 --pmc %s: %r" % (group, e)
-            got = {}
+            for ln in p.stdout.splitlines():
+                if ln.startswith("{") and '"folds"' in ln:
+                    j = json.loads(ln)
+                    folds, launches = j["folds"], j["launches"]
+            got, disp = {}, set()
             for f in glob.glob(os.path.join(out, "*", "*counter_collection.csv")):
                 for row in csv.DictReader(open(f)):
-                    # the timed launch of gpu_mfe_only.py is the one with a full persistent grid (its warm-up folds 1024 rows)
-                    if "sf_mfe_fast_kernel" in row["Kernel_Name"] and int(row["Grid_Size"]) >= 256 * 256:
+                    if "sf_mfe_fast_kernel" in row["Kernel_Name"]:
                         got[row["Counter_Name"]] = got.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+                        disp.add(row.get("Dispatch_Id"))
             missing = [c for c in group.split() if got.get(c, 0.0) <= 0.0]
-            if missing:
+            if missing or not folds:
                 return None, "rocprofv3 --pmc %s gave no rows for %s (rc %d: %s)" % (group, missing, p.returncode, p.stderr[-200:])
+            if launches and len(disp) != launches:
+                return None, "rocprofv3 --pmc %s: %d dispatches of the kernel for %d launches" % (group, len(disp), launches)
             vals.update(got)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    return {k: v / n_folds for k, v in vals.items()}, None
+    out = {k: v / folds for k, v in vals.items()}
+    out["_folds"], out["_launches"] = folds, launches
+    return out, None
+
+
+def calibrated_unit_fractions(sec, W, folds_per_launch, launch_ms, eng, n_cu=256):
+    """How busy the vector ALUs and the LDS were during the timed launch: instructions per fold (SQ counters) x the folds of
+    a launch x the MEASURED cost of an instruction of this kernel's mix at its occupancy (profiles/r04/mfe_issue_rates.json:
+    tools/micro/issue_rates.hip, valu_classes.hip; vector mix from the ISA of the hot blocks) / the launch's duration by HIP
+    events.  (Rounds 1-3 assumed 4 cycles per vector instruction; the round-3 review held 2 against it.  Measured: the
+    packed int16 / min / bit-select instructions are half-rate, 1.8-1.95 ns per wave64 instruction and SIMD, 32-bit adds
+    and moves full-rate, 1.05 ns; this kernel's mix averages 1.72 ns.)"""
+    path = os.path.join(ROOT, "profiles", "r04", "mfe_issue_rates.json")
+    try:
+        rates = json.load(open(path))
+        name = eng.device_name()
+        if "CUs" in name:
+            n_cu = int(name.split(",")[-1].split()[0])
+    except Exception as e:
+        return {"calibration": "unavailable: %r" % e}
+    if launch_ms <= 0:
+        return {"calibration": "no launch time"}
+    launch_ns = launch_ms * 1e6
+    v_ns = rates["valu_ns_per_inst_per_simd"].get(str(W), rates["valu_ns_per_inst_per_simd"]["default"])
+    valu = sec["valu_insts_per_fold"] * folds_per_launch / (4.0 * n_cu) * v_ns / launch_ns
+    salu = sec["salu_insts_per_fold"] * folds_per_launch / (4.0 * n_cu) * rates["salu_ns_per_inst_per_simd"] / launch_ns
+    lds = sec["lds_idx_active_per_fold"] * folds_per_launch / n_cu * rates["lds_ns_per_idx_active_unit_per_cu"] / launch_ns
+    return {"valu_issue_frac": valu, "lds_frac": lds, "salu_issue_frac": salu,
+            "binding_unit": "valu" if valu >= lds else "lds",
+            "measured_peaks": {"valu_ns_per_wave_inst_per_simd": v_ns,
+                               "valu_full_rate_ns": rates["valu_full_rate_ns"], "valu_half_rate_ns": rates["valu_half_rate_ns"],
+                               "salu_ns_per_wave_inst_per_simd": rates["salu_ns_per_inst_per_simd"],
+                               "lds_ns_per_idx_active_unit_per_cu": rates["lds_ns_per_idx_active_unit_per_cu"],
+                               "lds_ns_per_inst_per_cu": rates["lds_ns_per_inst_per_cu"], "n_cu": n_cu},
+            "definition": "frac = instructions (or LDS index-active units) of one launch per SIMD (per CU) x measured ns per "
+                          "instruction at four waves per SIMD / launch duration; 1.0 = that unit issues back to back",
+            "calibration": "profiles/r04/mfe_issue_rates.json"}
 
 
 def reference_python_overhead(seq, W, r, windows=6):
@@ -265,7 +331,11 @@ def main():
                     help="take roofline.traffic from the committed profiles/ file instead of two live rocprofv3 --pmc child "
                          "runs (use when bench.py itself runs under rocprofv3)")
     ap.add_argument("--config", choices=sorted(WORKLOADS), default="cfg3",
-                    help="cfg3 (default, the metric's own configuration) or cfg5 (W=200, r=1000, partition function)")
+                    help="cfg3 (default, the metric's own configuration), cfg5 (W=200, r=1000, partition function), or the "
+                         "small parity shapes cfg1 / cfg2")
+    ap.add_argument("--shuffle", default="", help="di (the north star's; default) or mono (SURVEY.md 8d's secondary run)")
+    ap.add_argument("--input", choices=("uniform", "viral"), default="uniform",
+                    help="uniform i.i.d. ACGU (default) or SURVEY.md 8d's viral-like input (60 %% AU + planted hairpins)")
     args = ap.parse_args()
     if args.steps is None:
         args.steps = 2 if args.config == "cfg3" else 1
@@ -300,10 +370,18 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
     eng = _lib.Engine(device=local_rank)
 
-    wl = WORKLOADS[args.config]
+    wl = dict(WORKLOADS[args.config])
+    if args.shuffle:
+        if args.shuffle not in ("di", "mono"):
+            print("bench.py: --shuffle must be di or mono", file=sys.stderr)
+            return 2
+        wl["name"] = wl["name"].replace("%s-shuffles" % wl["shuffle"], "%s-shuffles" % args.shuffle)
+        wl["shuffle"] = args.shuffle
+    if args.input != "uniform":
+        wl["name"] = wl["name"].replace("synthetic RNA", "synthetic %s-like RNA" % args.input)
     W, step, r = wl["W"], wl["step"], wl["r"]
     kind = _lib.SHUFFLE_DI if wl["shuffle"] == "di" else _lib.SHUFFLE_MONO
-    seq = synth_transcript(wl["L"], wl["seed"])
+    seq = synth_transcript(wl["L"], wl["seed"], args.input)
     n_win = (len(seq) - W) // step + 1
     lo, hi = sdist.shard_range(n_win, rank, world)
     n_loc = hi - lo
@@ -335,8 +413,9 @@ def main():
     sync()
     eng.prof_reset()
     t0 = time.perf_counter()
+    gathered = None
     for _ in range(args.steps):
-        step_fn()
+        gathered = step_fn()
     sync()
     elapsed = time.perf_counter() - t0
     if use_dist:
@@ -370,27 +449,50 @@ def main():
         traffic_src = counters_src and (counters_src + " (rocprofv3 --pmc passes of an earlier run, committed)")
         secondary_src = counters_src and (counters_src + " (SQ counter passes of an earlier run, committed)")
         if world == 1 and not args.no_live_counters:
-            nf = 131072 if W <= 128 else 65536
-            live, why = live_counters_per_fold(W, ["FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE",
-                                                   "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU"], nf)
+            # cfg5's step is half a minute: its counters are taken on the first 2 000 windows of the same scan
+            live, why = live_counters_per_fold(args.config, args.shuffle, args.input,
+                                               ["FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE",
+                                                "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU"],
+                                               windows=(2000 if W > 128 else 0))
             if live is not None:
-                how = ("live: rocprofv3 --pmc child runs of tools/gpu_mfe_only.py %d %d after the timed region, one counter group "
-                       "per run" % (nf, W))
+                how = ("live: rocprofv3 --pmc child runs of tools/gpu_scan_only.py %s (ONE scan of the timed workload, no warm-up: "
+                       "%d sf_mfe_fast_kernel launch(es), %d folds) after the timed region, one counter group per run"
+                       % (args.config, live["_launches"], live["_folds"]))
                 # gfx950 reports half of a read: bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB; L2 <-> fabric, Infinity-Cache hits included
                 traffic = (2.0 * live["FETCH_SIZE"] + live["WRITE_SIZE"]) * 1024.0 * folds_per_launch
                 traffic_src = how + "; (2 x FETCH_SIZE + WRITE_SIZE) KB per fold x the folds of one launch"
                 wc = live["SQ_WAVE_CYCLES"]
-                secondary = {"valu_busy": 4 * live["SQ_ACTIVE_INST_VALU"] / wc,
-                             "lanes_active_of_64": live["SQ_THREAD_CYCLES_VALU"] / max(live["SQ_ACTIVE_INST_VALU"], 1.0),
-                             "lds_busy": 4 * live["SQ_LDS_IDX_ACTIVE"] / wc, "waves_parked": live["SQ_WAIT_ANY"] / wc,
+                secondary = {"lanes_active_of_64": live["SQ_THREAD_CYCLES_VALU"] / max(live["SQ_ACTIVE_INST_VALU"], 1.0),
+                             "waves_parked": live["SQ_WAIT_ANY"] / wc,
                              "valu_insts_per_fold": live["SQ_INSTS_VALU"], "lds_insts_per_fold": live["SQ_INSTS_LDS"],
-                             "salu_insts_per_fold": live["SQ_INSTS_SALU"],
-                             "definition": "SQ counters of the MFE kernel per fold on random %d-mers; a SIMD hosts four of its "
-                                           "waves: busy = 4 x unit-active quad-cycles / wave quad-cycles of a fold" % W}
+                             "salu_insts_per_fold": live["SQ_INSTS_SALU"], "lds_idx_active_per_fold": live["SQ_LDS_IDX_ACTIVE"]}
                 secondary_src = how
+                secondary.update(calibrated_unit_fractions(secondary, W, folds_per_launch, avg_ms, eng))
             else:
                 traffic_src = (traffic_src or "none") + "; live measurement failed: " + why
-        checked, bad = verify_sample(seq, W, step, r, kind, wl["shuffle_seed"], lo, n_loc, en, db, cen, div, wl["verify"])
+        gather_check = None
+        if use_dist and gathered is not None:
+            # what the RCCL all-gather delivered, un-padded and put back into window order, against (i) this rank's own
+            # device tensors for its shard and (ii) the oracle on windows spread over EVERY rank's shard (below)
+            merged = sdist.merge_shards(gathered, n_win, world, W, r)
+            mine = slice(lo, hi)
+            same = bool((merged["energies"][mine] == en[:n_loc].cpu().numpy()).all()
+                        and (merged["structure"][mine] == db[:n_loc].cpu().numpy()).all()
+                        and (merged["centroid"][mine] == cen[:n_loc].cpu().numpy()).all()
+                        and (merged["ens_div"][mine] == div[:n_loc].cpu().numpy()).all()
+                        and (merged["ens_dG"][mine] == dG[:n_loc].cpu().numpy()).all())
+            gather_check = {"backend": dist.get_backend(), "ranks": world, "windows": n_win,
+                            "bytes_per_rank": int(gathered.shape[0] // world * gathered.shape[1]),
+                            "rank0_shard_equals_its_device_tensors": same}
+            # verify on the gathered records of all shards: torch tensors on the host in the layout verify_sample reads
+            v_en, v_db = torch.from_numpy(merged["energies"]), torch.from_numpy(merged["structure"])
+            v_cen, v_div = torch.from_numpy(merged["centroid"]), torch.from_numpy(merged["ens_div"])
+            checked, bad = verify_sample(seq, W, step, r, kind, wl["shuffle_seed"], 0, n_win, v_en, v_db, v_cen, v_div,
+                                         wl["verify"])
+            if not same:
+                bad += 1
+        else:
+            checked, bad = verify_sample(seq, W, step, r, kind, wl["shuffle_seed"], lo, n_loc, en, db, cen, div, wl["verify"])
         algorithmic_bytes = folds_per_launch * bytes_per_fold
         out = {
             "metric": wl["metric"],
@@ -415,8 +517,10 @@ def main():
                          "secondary": secondary,
                          "mfe_kernel_share_of_step": (kern_ms * 1e-3) / elapsed},
             "verified_windows": checked, "verified_mismatches": bad, "device_status": dev_status,
+            "gather_check": gather_check,
             "verified_against": "oracle (sf_oracle.c + sf_shuffle_oracle.c): all %d energies, structure, centroid, "
-                                "ensemble diversity of %d windows of the last timed step" % (r + 1, checked),
+                                "ensemble diversity of %d windows of the last timed step%s"
+                                % (r + 1, checked, " (taken from the gathered records of all ranks)" if gather_check else ""),
             "params": eng.params.source and os.path.basename(eng.params.source),
             "device": eng.device_name(),
         }

@@ -46,7 +46,8 @@ struct Ctx {
     SfDevParams *dP = nullptr;
     SfDevParamsPF *dX = nullptr;
     SfFastParams *dF = nullptr;
-    uint64_t key = 0;
+    uint64_t key = 0;                 // FNV-1a of the blobs it was built from: finds the candidate ...
+    std::vector<unsigned char> src;   // ... and their bytes decide (1 blob, or 3 for a rescaled set)
     bool valid = false;
     int fast_ok = 0;
     int span = 0;          // the max_bp_span its max_pair_dist field was written for
@@ -56,7 +57,9 @@ struct Ctx {
   uint64_t loads = 0;
   int cur = 0;
   double temperature = 37.0;
-  DevBuf full_scratch, pf_scratch, pf_share, fast_scratch, seqs, energies, db, cen, dbl, status, transcript, ovf, cons, sc;
+  DevBuf full_scratch, pf_scratch, pf_share, fast_scratch, fast_rows, seqs, energies, db, cen, dbl, status, transcript, ovf, cons, sc;
+  int fast_rows_W = 0;            // the width g.fast_rows holds the rolling-row offsets for (0: none)
+  SfFastRows fast_rows_host;
   DevBuf tab_in, tab_partner, tab_counts, tab_out;  // sf_tabulate_pairs
   int64_t tab_groups = -1;
   std::string last_hip_error;
@@ -332,6 +335,14 @@ struct ProfPair {
   }
 };
 
+// SCANFOLD_MFE_POISON=1..5 (tests only): the LDS kernel's poison build — every byte a fold has not written itself holds an
+// adversarial pattern (sf_mfe_fast.hip.h, PZ).  Read at every launch so that a test can switch it inside one process.
+static int mfe_poison() {
+  const char *e = getenv("SCANFOLD_MFE_POISON");
+  const int v = e ? atoi(e) : 0;
+  return v >= 1 && v <= 5 ? v : 0;
+}
+
 // d_cons / d_sc: every fold has its own hard constraint / Deigan pseudo-energies (row k of each; trace_stride 1): the
 // constrained native windows of sf_fold_constrained, on the LDS kernel where it applies (W <= 250), else the general one
 int launch_mfe(const uint8_t *d_seqs, int n, int W, int32_t *d_out, hipStream_t st, int trace_stride = 1,
@@ -356,14 +367,23 @@ int launch_mfe(const uint8_t *d_seqs, int n, int W, int32_t *d_out, hipStream_t 
     HIPCHK(hipMemsetAsync(d_cnt, 0, 2 * sizeof(int), st));
     rc = ensure(g.fast_scratch, scratch_bytes);
     if (rc) return rc;
+    // the rolling rows' offsets for this width (SfFastRows; stream-ordered behind the launches that read the previous table)
+    rc = ensure(g.fast_rows, sizeof(SfFastRows));
+    if (rc) return rc;
+    if (g.fast_rows_W != W) {
+      sf_fast_build_rows(W, g.fast_rows_host);
+      HIPCHK(hipMemcpyAsync(g.fast_rows.p, &g.fast_rows_host, sizeof(SfFastRows), hipMemcpyHostToDevice, st));
+      HIPCHK(hipStreamSynchronize(st));  // (the host copy is reused by the next width)
+      g.fast_rows_W = W;
+    }
     if ((rc = prof.begin(st))) return rc;
     if (hc)
       sf_fast_launch_hc(grid, threads, lds, st, d_seqs, n, W, (const SfDevParams *)g.dP, (const SfFastParams *)g.dF,
-                        (int16_t *)g.fast_scratch.p, d_out, d_cnt, d_list, trace_stride, d_db, (int *)g.status.p, d_work,
+                        (const SfFastRows *)g.fast_rows.p, (int16_t *)g.fast_scratch.p, d_out, d_cnt, d_list, trace_stride, d_db, (int *)g.status.p, d_work,
                         d_cons, d_sc);
     else
-      sf_fast_launch(grid, threads, lds, st, d_seqs, n, W, (const SfDevParams *)g.dP, (const SfFastParams *)g.dF,
-                     (int16_t *)g.fast_scratch.p, d_out, d_cnt, d_list, trace_stride, d_db, (int *)g.status.p,
+      sf_fast_launch(mfe_poison(), grid, threads, lds, st, d_seqs, n, W, (const SfDevParams *)g.dP, (const SfFastParams *)g.dF,
+                     (const SfFastRows *)g.fast_rows.p, (int16_t *)g.fast_scratch.p, d_out, d_cnt, d_list, trace_stride, d_db, (int *)g.status.p,
                      d_work, (const char *)nullptr, (const int32_t *)nullptr);
     HIPCHK(hipGetLastError());
     if ((rc = prof.end(st))) return rc;
@@ -455,7 +475,7 @@ int sf_init(int device_ordinal) {
 int sf_shutdown(void) {
   if (!g.init) return SF_OK;
   hipDeviceSynchronize();
-  DevBuf *bufs[] = {&g.full_scratch, &g.pf_scratch, &g.pf_share, &g.fast_scratch, &g.seqs, &g.energies, &g.db, &g.cen,
+  DevBuf *bufs[] = {&g.full_scratch, &g.pf_scratch, &g.pf_share, &g.fast_scratch, &g.fast_rows, &g.seqs, &g.energies, &g.db, &g.cen,
                     &g.dbl, &g.status, &g.transcript, &g.ovf, &g.cons, &g.sc, &g.tab_in, &g.tab_partner, &g.tab_counts,
                     &g.tab_out};
   for (DevBuf *b : bufs) {
@@ -475,6 +495,7 @@ int sf_shutdown(void) {
   if (g.stream) hipStreamDestroy(g.stream);
   g.stream = nullptr;
   g.init = false;
+  g.fast_rows_W = 0;
   g.have_params = false;
   return SF_OK;
 }
@@ -502,6 +523,8 @@ int sf_params_load_rescaled(const void *blob, size_t nbytes, double temperature_
     memcpy(&P37, blob_37c, sizeof P37);
     memcpy(&PdH, blob_enthalpy, sizeof PdH);
     if (P37.magic != SF_PARAMS_MAGIC || P37.version != SF_PARAMS_VERSION) return SF_ERR_BAD_PARAMS;
+    if (PdH.magic != SF_PARAMS_MAGIC || PdH.version != SF_PARAMS_VERSION) return SF_ERR_BAD_PARAMS;
+    if (fabs(P37.temperature - 37.0) > 1e-9) return SF_ERR_TEMPERATURE;  // the record the rescale starts from
   }
   if (fabs(P.temperature - temperature_c) > 1e-9) return SF_ERR_TEMPERATURE;
   // the set's identity: FNV-1a over the bytes handed in
@@ -515,8 +538,15 @@ int sf_params_load_rescaled(const void *blob, size_t nbytes, double temperature_
   const int32_t md = g.max_bp_span > 0 ? g.max_bp_span - 1 : 0x7fffffff;
   g.loads++;
   int hit = -1;
-  for (int k = 0; k < 2; k++)
-    if (g.slot[k].valid && g.slot[k].key == key) hit = k;
+  // (the hash only finds the candidate: a slot is this set iff the bytes it was built from are these bytes)
+  const size_t nb = sizeof(sf_params_blob);
+  for (int k = 0; k < 2; k++) {
+    auto &m = g.slot[k];
+    if (!m.valid || m.key != key || m.src.size() != (blob_37c ? 3 : 1) * nb) continue;
+    if (memcmp(m.src.data(), &P, nb) != 0) continue;
+    if (blob_37c && (memcmp(m.src.data() + nb, &P37, nb) != 0 || memcmp(m.src.data() + 2 * nb, &PdH, nb) != 0)) continue;
+    hit = k;
+  }
   if (hit < 0) {
     // the slot not in use (or the older one) is rebuilt; queued work may still read it
     const int k = !g.slot[0].valid ? 0 : (!g.slot[1].valid ? 1 : (g.have_params ? 1 - g.cur : (g.slot[0].used <= g.slot[1].used ? 0 : 1)));
@@ -531,6 +561,11 @@ int sf_params_load_rescaled(const void *blob, size_t nbytes, double temperature_
     HIPCHK(hipMemcpy(g.slot[k].dP, &D, sizeof D, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(g.slot[k].dX, &X, sizeof X, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(g.slot[k].dF, &F, sizeof F, hipMemcpyHostToDevice));
+    g.slot[k].src.assign((const unsigned char *)&P, (const unsigned char *)&P + nb);
+    if (blob_37c) {
+      g.slot[k].src.insert(g.slot[k].src.end(), (const unsigned char *)&P37, (const unsigned char *)&P37 + nb);
+      g.slot[k].src.insert(g.slot[k].src.end(), (const unsigned char *)&PdH, (const unsigned char *)&PdH + nb);
+    }
     g.slot[k].key = key; g.slot[k].valid = true; g.slot[k].fast_ok = F.fast_ok; g.slot[k].span = g.max_bp_span;
     g.slot[k].temperature = temperature_c;
     hit = k;
@@ -686,6 +721,14 @@ int sf_fold_constrained(const uint8_t *seqs, int n, int W, const char *cons, con
       sf_pf_lds_launch_hc(grid, W, g.stream, (const uint8_t *)g.seqs.p, n, 1, W, (const SfDevParams *)g.dP,
                           (const SfDevParamsPF *)g.dX, d_dG, d_mbd, (char *)g.cen.p, d_cd, (const uint8_t *)nullptr, 0, 0, 1, 1,
                           (double *)nullptr, d_cons, (int *)g.status.p);
+    } else if (!noncanonical && !g.force_full && W >= 16 && W <= SF_PFF_HC_MAXW) {
+      // the constrained instantiation of the device-table kernel (120 < W <= 250, or SCANFOLD_PF_KERNEL=global)
+      const int pf_blocks = g.n_cu * g.pf_blocks_per_cu;
+      grid = n < pf_blocks ? n : pf_blocks;
+      if ((rc = ensure(g.pf_scratch, (size_t)grid * SF_PFF_SCRATCH_DOUBLES(W) * sizeof(double)))) return rc;
+      sf_pf_fast_launch_hc(grid, W, g.stream, (const uint8_t *)g.seqs.p, n, 1, W, (const SfDevParams *)g.dP,
+                           (const SfDevParamsPF *)g.dX, (double *)g.pf_scratch.p, d_dG, d_mbd, (char *)g.cen.p, d_cd, d_cons,
+                           (int *)g.status.p);
     } else {
       if ((rc = ensure(g.pf_scratch, (size_t)grid * SF_PF_SCRATCH_DOUBLES(W) * sizeof(double)))) return rc;
       SF_LAUNCH(sf_pf_kernel, grid, block_threads(W), 0, g.stream, (const uint8_t *)g.seqs.p, n, 1, W,

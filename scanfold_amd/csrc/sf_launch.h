@@ -12,6 +12,8 @@
 #define SF_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier((mask), (n), 0)
 // nothing is scheduled across this point (bounds how many loads the compiler keeps in flight = live registers)
 #define SF_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// vector ALU instructions keep their order across this point; loads, LDS and scalar instructions may still move
+#define SF_VALU_FENCE() __builtin_amdgcn_sched_barrier(0x7fc)
 // the value must be computed by this point (keeps the arithmetic next to the loads that feed it)
 #define SF_PIN(x) asm volatile("" : "+v"(x))
 // A wave-uniform pointer into constant device memory whose value the optimiser has to take as given at this point: addresses

@@ -53,6 +53,9 @@
 // even diagonals below this one skip whole batches of loop sizes above the limit (CH); from here to 36 the skipped
 // work is small and the unbroken straight-line code is faster (measured: 20 / 24 / 28 / 36 -> 87.5 / 87.1 / 87.0 / 87.9 ms)
 #define SF_FAST_CHUNK_D0 36
+#ifndef SF_FAST_ROWTAB
+#define SF_FAST_ROWTAB 1  // rolling-row offsets from a table (scalar loads, SfFastRows) instead of per-row ring arithmetic
+#endif
 #define SF_FAST_SPLIT 1  // long diagonals: the idle second wave of a group takes part of the cell's work
 #define SF_FAST_DML2 1   // ... and the first runs the multiloop split two cells per lane, the lanes in chunks over the terms
 // split steps at W <= 128: 1 = ONE helper wave serves both diagonals of a step, on a compacted list of the cells that
@@ -82,7 +85,14 @@
 #define SF_FAST_MAXPARAM 2500
 #define SF_FAST_MAXW 256
 #define SF_FAST_BIG 60000
+#ifndef SF_FAST_WAVES_PER_SIMD
 #define SF_FAST_WAVES_PER_SIMD 4  // 4 workgroups of 4 waves per CU (W <= 128): at most 128 VGPRs
+#endif
+// timing experiment only (wrong energies): the bulge / 1xn ring aliased onto the fML triangle, so that the footprint allows
+// five or six workgroups per CU — what would a smaller layout buy?  (profiles/r04/mfe_occupancy_bound.txt)
+#ifndef SF_EXP_ALIAS
+#define SF_EXP_ALIAS 0
+#endif
 
 struct SfFastParams {
   int32_t NIN[32];   // [a]  min(max_ninio, a * ninio)
@@ -191,6 +201,25 @@ static inline void sf_fast_build_params(const SfDevParams &D, SfFastParams &F) {
     }
 }
 
+// Byte offsets of the rolling rows for one window width (device memory, rebuilt by the host when the width changes): the row of
+// loop size u for a cell whose diagonal d-2 sits in ring slot s is row (s - u) mod NR — offset * (W-4) * 2 bytes in the
+// generic-loop view, * 4 in the interleaved bulge / 1xn view.  The cell code used to derive every row on the scalar unit
+// (compare, select, add, multiply: ~5 instructions per row, a third of the scalar instructions of a fold); read from here with
+// wave-uniform addresses they are scalar loads of 8-16 dwords.  By slot and size class ([slot][u >> 1], odd and even u apart:
+// the narrow kernel uses the odd sizes' rows — an even size's row is the next one — and a few even ones), so that the rows one
+// pass needs are runs of consecutive dwords.
+struct SfFastRows {
+  int32_t ci_odd[SF_FAST_NR][16], ci_even[SF_FAST_NR][16], bn_odd[SF_FAST_NR][16], bn_even[SF_FAST_NR][16];
+};
+static inline void sf_fast_build_rows(int W, SfFastRows &R) {
+  for (int sl = 0; sl < SF_FAST_NR; sl++)
+    for (int u = 0; u < 32; u++) {
+      const int row = ((sl - u) % SF_FAST_NR + SF_FAST_NR) % SF_FAST_NR;
+      ((u & 1) ? R.ci_odd : R.ci_even)[sl][u >> 1] = row * (W - 4) * 2;
+      ((u & 1) ? R.bn_odd : R.bn_even)[sl][u >> 1] = row * (W - 4) * 4;
+    }
+}
+
 // LDS carve (bytes); every piece a multiple of 4
 struct SfFastLayout {
   int tri;  // int16 entries of the fML triangle (diagonals >= 4)
@@ -222,8 +251,8 @@ static inline __host__ __device__ SfFastLayout sf_fast_layout(int W, bool hc = f
   // (ring row 0 only ever holds the diagonals NR, 2 NR, ...: at most W - NR cells, so that is all the mirror rows keep)
   const int mirror = (W <= 128 && W > SF_FAST_NR) ? ((W - SF_FAST_NR + 1) & ~1) : 0;  // entries
   L.off_ci = o; o += roll + mirror * 2;  // the exterior pass reuses this area for f5[] and the mismatchExt table
-  L.off_c1n = o; o += roll;
-  L.off_cb = o; o += roll;
+  L.off_c1n = SF_EXP_ALIAS ? 0 : o; o += SF_EXP_ALIAS ? 0 : roll;
+  L.off_cb = o; o += SF_EXP_ALIAS ? 0 : roll;
   L.off_dml = o;  // (end of the rolling tables; the rolling rows of multiloop-split minima that used to follow are gone)
   // the interleaved bulge / 1xn table gets row NR = a copy of its row 0 as well ("the row after row r" exists for every r: the
   // merged helper relies on it too); W < SF_HELP_MERGE_MAXW (merged helper): each of the two helper waves a 128-byte list of cells
@@ -261,6 +290,7 @@ struct SfFastCtx {
   const uint8_t *tPair, *S;
   const SfDevParams *D;
   const SfFastParams *F;
+  const SfFastRows *R;
   int16_t *cg;
   int W, TAU, MLbase, MLclosing, MLintern;
   int fold;     // 1: the fML area is the folded rectangle (W > 128), 0: the triangle
@@ -379,7 +409,10 @@ struct SfPub {
 // UCAP (G code only): compile-time bound on the loop sizes that can exist — d <= 7: 1, d <= 11: 5 — so that the unrolled
 // size tests above it (a scalar compare + branch each, ~110 of them) disappear from the first four steps of a fold, which
 // cost as much as full steps before (profiles/r03/mfe_step_profile.txt).
-template <bool G, int WT, int SEC, bool CH = false, bool FOLD = false, int UCAP = SFD_MAXLOOP>
+// TBLK: the rolling rows' offsets come from the SfFastRows table (scalar loads) instead of the ring arithmetic — the kernel
+// decides per instantiation (measured: +4 % at W = 120 / 200, +3 % at W = 128; the merged-helper and the generic wide
+// instantiations, which already spill, lose 1-2 % and keep the arithmetic)
+template <bool G, int WT, int SEC, bool CH = false, bool FOLD = false, int UCAP = SFD_MAXLOOP, bool TBLK = true>
 __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, const int i, const bool valid,
                                              const int slot2, const int slotd, uint32_t (&HP)[14], int &ovf,
                                              const bool final_fml, const int fnb, int &fpart, int &dec, int &eh, int &e0,
@@ -450,6 +483,14 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
 // (a v_readlane lane table for these offsets measured +1 % at W=120, -2 % at W=200, and is unsafe wherever the
 // build spills registers — see SF_UNI — so the scalar unit keeps computing them)
 #define ROW(u) ((slot2 - (u) < 0 ? slot2 - (u) + SF_FAST_NR : slot2 - (u)) * RW)
+  // TBL (the all-sizes code): the rows' byte offsets come from SfFastRows — scalar loads of consecutive entries
+  constexpr bool TBL = !G && TBLK && SF_FAST_ROWTAB;
+  const SfFastRows *const Rc = TBL ? sf_const_base(X.R) : X.R;  // (the base is pinned by a volatile asm: only where it is used)
+  const int32_t *const rci_o = Rc->ci_odd[slot2], *const rci_e = Rc->ci_even[slot2];
+  const int32_t *const rbn_o = Rc->bn_odd[slot2], *const rbn_e = Rc->bn_even[slot2];
+#define ROWB_CI(u) (TBL ? (((u)&1) ? rci_o[(u) >> 1] : rci_e[(u) >> 1]) : 2 * ROW(u))
+#define ROWB_BN(u) (TBL ? (((u)&1) ? rbn_o[(u) >> 1] : rbn_e[(u) >> 1]) : 4 * ROW(u))
+#define CIROW(u) ((const int16_t *)((const char *)X.CI + ROWB_CI(u)))
 
   if (SEC & SF_SEC_P1) {
   // ---- pass 1 (every cell): per-size minima of the generic interior candidates ----
@@ -468,7 +509,7 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
     // asymmetry terms of both sizes are one aligned 32-bit read of the int16 table.  Descending order, so
     // HP[p-1] still holds the enclosed cell's minima.  Size 30 (x = 26) has no partner.
     if (!CH || um >= 30) {
-      const int16_t *row = X.CI + ROW(30) + i0;
+      const int16_t *row = CIROW(30) + i0;
       const int e = sfd_min(row[3], row[29]) + SF_UNI(uNIN, 26);
       HSET(26, sfd_min(e, HGET(24)));
     }
@@ -480,7 +521,7 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
       for (int k = 0; k < 3; k++) {
         const int u = 2 * (pb - k) + 4;
         // (!FOLD: row u is the row after row u+1 — the mirror row when that is the ring's last — at a compile-time offset)
-        const int16_t *rb = X.CI + ROW(u + 1) + i0, *ra = FOLD ? X.CI + ROW(u) + i0 : rb + RW;
+        const int16_t *rb = CIROW(u + 1) + i0, *ra = FOLD ? CIROW(u) + i0 : rb + RW;
         e1[k] = sf_pk(ra[3], rb[3]);          // u1 = 2
         e2[k] = sf_pk(ra[u - 1], rb[u]);      // u2 = 2
         nn[k] = sf_ldw(uNIN + (u - 4));
@@ -493,10 +534,10 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
     }
   }
   if (!G || (UCAP >= 5 && umax >= 5)) {
-    const int16_t *row = X.CI + ROW(5) + i0;
+    const int16_t *row = CIROW(5) + i0;
     HSET(1, sfd_min(row[3], row[4]) + SF_UNI(uNIN, 1));
   }
-  if (!G || (UCAP >= 4 && umax >= 4)) HSET(0, X.CI[ROW(4) + i0 + 3] + SF_UNI(uNIN, 0));
+  if (!G || (UCAP >= 4 && umax >= 4)) HSET(0, (CIROW(4) + i0)[3] + SF_UNI(uNIN, 0));
 
   }
 
@@ -508,13 +549,13 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
     // because the two-word reads have no room for the base in their offset fields).
 #ifdef SF_EMUL
     const int bno = 4 * i0;
-#define BNROW(r) ((const int16_t *)((const char *)X.BN + (bno + 4 * (r))))
+#define BNROWB(b) ((const int16_t *)((const char *)X.BN + (bno + (b))))
 #else
     // (the table's own LDS offset goes into the pinned value too — the low half of a flat LDS address is the LDS offset — so
     // that nothing but the row's scalar offset is left to add)
     unsigned bno = (unsigned)(uintptr_t)(const void *)X.BN + 4u * (unsigned)i0;
     if (!G) SF_PIN(bno);
-#define BNROW(r) ((const int16_t *)(const __attribute__((address_space(3))) int16_t *)(uintptr_t)(bno + 4u * (unsigned)(r)))
+#define BNROWB(b) ((const int16_t *)(const __attribute__((address_space(3))) int16_t *)(uintptr_t)(bno + (unsigned)(b)))
 #endif
     if (type && (!G || umax >= 0)) {
       const int TAU = X.TAU;
@@ -526,11 +567,11 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
       {  // stack (+ the Deigan pseudo-energies of its four nucleotides: fc.sc_add_SHAPE_deigan, ScanFold.py:533-539)
         const int t2r = RP[si1 * 8 + sj1];
         const int sc4 = X.sc ? X.sc[i] + X.sc[i + 1] + X.sc[j - 1] + X.sc[j] : 0;
-        eh = sfd_min(eh, BNROW(ROW(0))[2 * 1] + st[t2r] + sc4);
+        eh = sfd_min(eh, BNROWB(ROWB_BN(0))[2 * 1] + st[t2r] + sc4);
       }
       if (!G || umax >= 1) {  // one-nucleotide bulges keep the stack
         const int b1 = SF_UNI(uBN, 2);
-        const int16_t *row = BNROW(ROW(1));
+        const int16_t *row = BNROWB(ROWB_BN(1));
         const int ta = RP[si1 * 8 + S[j - 2]];  // (i+1, j-2)
         eh = sfd_min(eh, row[2 * 1] + b1 + st[ta]);
         const int tb = RP[S[i + 2] * 8 + sj1];  // (i+2, j-1)
@@ -538,10 +579,10 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
       }
       if (!G || (UCAP >= 2 && umax >= 2)) {  // 1 x 1: (i+2, j-2)
         const unsigned t2r = RP[S[i + 2] * 8 + S[j - 2]];
-        eh = sfd_min(eh, BNROW(ROW(2))[2 * 2] + Fc->int11T[((tq + t2r) * 5u + si1) * 5u + sj1]);
+        eh = sfd_min(eh, BNROWB(ROWB_BN(2))[2 * 2] + Fc->int11T[((tq + t2r) * 5u + si1) * 5u + sj1]);
       }
       if (!G || (UCAP >= 3 && umax >= 3)) {  // 1 x 2 and 2 x 1
-        const int16_t *row = BNROW(ROW(3));
+        const int16_t *row = BNROWB(ROWB_BN(3));
         const unsigned ta = RP[S[i + 2] * 8 + S[j - 3]];  // (i+2, j-3), sq1 = S[j-2]
         eh = sfd_min(eh, row[2 * 2] + Fc->int21a[(((tq + ta) * 5u + si1) * 5u + S[j - 2]) * 5u + sj1]);
         const unsigned tb = RP[S[i + 3] * 8 + S[j - 2]];  // (i+3, j-2), sp1 = S[i+2]
@@ -549,11 +590,11 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
       }
       if (!G || (UCAP >= 4 && umax >= 4)) {  // 2 x 2: (i+3, j-3)
         const unsigned t2r = RP[S[i + 3] * 8 + S[j - 3]];
-        eh = sfd_min(eh, BNROW(ROW(4))[2 * 3] +
+        eh = sfd_min(eh, BNROWB(ROWB_BN(4))[2 * 3] +
                              Fc->int22T[((((tq + t2r) * 5u + si1) * 5u + S[i + 2]) * 5u + S[j - 2]) * 5u + sj1]);
       }
       if (!G || (UCAP >= 5 && umax >= 5)) {  // 2 x 3 and 3 x 2
-        const int16_t *row = BNROW(ROW(5));
+        const int16_t *row = BNROWB(ROWB_BN(5));
         const int m23 = X.t23[SF_TIDX(type, si1, sj1)] + Fc->L23;
         const int ta = RP[S[i + 3] * 8 + S[j - 4]];  // (i+3, j-4); sp1 = S[i+2], sq1 = S[j-3]
         eh = sfd_min(eh, row[2 * 3] + m23 + X.t23in[SF_TIDX(ta, S[j - 3], S[i + 2])]);
@@ -576,34 +617,65 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
         // they are the low / high halves of the word pairs (1, 2) and (u, u+1) — two two-word reads; one
         // bit-select each puts (bulge, 1xn) candidates side by side, and the rest is packed: min, saturating
         // add of the (bulge[u], 1xn[u]) weights (one uniform read), min.  Batches of SF_HELP_NB sizes.
-        uint32_t acc = sf_pk(32767, 32767);
+        // (gfx950: a packed VOP3P result read by the very next instruction costs one s_nop — the per-size chain min -> add ->
+        // min(acc) has two of them per size.  STAGED (the W = 120 instantiation): the sizes of a batch go through each stage
+        // together, two accumulators take turns, and a fence keeps the vector stages in that order: same vector instructions,
+        // 30 fewer idle issue slots per cell pass, +1 %.  The other instantiations measured 1-2 % SLOWER with it — their
+        // longer live ranges spill — and keep the chain.)
+        constexpr bool STAGED = (WT == 120);
+        uint32_t acc = sf_pk(32767, 32767), accb = acc;
         constexpr int SF_HELP_NB = FOLD ? SF_HELP_NB_256 : SF_HELP_NB_128;
 #pragma unroll
         for (int ub = 2; ub <= 30; ub += SF_HELP_NB) {
           if (CH && ub > um) continue;
-          uint32_t w0[SF_HELP_NB], w1[SF_HELP_NB], w2[SF_HELP_NB], w3[SF_HELP_NB], wt[SF_HELP_NB];
+          uint32_t w0[SF_HELP_NB], w1[SF_HELP_NB], w2[SF_HELP_NB], w3[SF_HELP_NB], wt[SF_HELP_NB], t[SF_HELP_NB];
 #pragma unroll
           for (int k = 0; k < SF_HELP_NB; k++) {
             const int u = ub + k;
             if (u <= 30) {
               // (!FOLD: sizes (u, u+1), u even, share a base — row u is the row after row u+1, the mirror row at the ring's seam)
-              const int16_t *t = (FOLD || u == 30) ? BNROW(ROW(u)) : BNROW(ROW(u | 1)) + ((u & 1) ? 0 : 2 * RW);
-              w0[k] = sf_ldw(t + 2 * 1);
-              if (!SHIFT) w1[k] = sf_ldw(t + 2 * 2);
-              w2[k] = sf_ldw(t + 2 * (SHIFT ? u - 1 : u)); w3[k] = sf_ldw(t + 2 * (u + 1));
+              const int16_t *tp = (FOLD || u == 30) ? BNROWB(ROWB_BN(u)) : BNROWB(ROWB_BN(u | 1)) + ((u & 1) ? 0 : 2 * RW);
+              w0[k] = sf_ldw(tp + 2 * 1);
+              if (!SHIFT) w1[k] = sf_ldw(tp + 2 * 2);
+              w2[k] = sf_ldw(tp + 2 * (SHIFT ? u - 1 : u)); w3[k] = sf_ldw(tp + 2 * (u + 1));
               wt[k] = sf_ldw(uBN + 2 * u);
             }
           }
+          if (STAGED) {
 #pragma unroll
-          for (int k = 0; k < SF_HELP_NB; k++) {
-            const int u = ub + k;
-            if (u <= 30) {
-              const uint32_t x = SHIFT ? w0[k] : ((w0[k] & 0xffffu) | (w1[k] & 0xffff0000u));  // (CB[1], C1N[2])
-              const uint32_t y = (w3[k] & 0xffffu) | (w2[k] & 0xffff0000u);  // (CB[1+u], C1N[u])
-              acc = sf_pkmin(acc, sf_pkadd(sf_pkmin(x, y), wt[k]));
+            for (int k = 0; k < SF_HELP_NB; k++) {
+              const int u = ub + k;
+              if (u <= 30) {
+                const uint32_t x = SHIFT ? w0[k] : ((w0[k] & 0xffffu) | (w1[k] & 0xffff0000u));  // (CB[1], C1N[2])
+                const uint32_t y = (w3[k] & 0xffffu) | (w2[k] & 0xffff0000u);  // (CB[1+u], C1N[u])
+                t[k] = sf_pkmin(x, y);
+              }
+            }
+            SF_VALU_FENCE();
+#pragma unroll
+            for (int k = 0; k < SF_HELP_NB; k++)
+              if (ub + k <= 30) t[k] = sf_pkadd(t[k], wt[k]);
+            SF_VALU_FENCE();
+#pragma unroll
+            for (int k = 0; k + 1 < SF_HELP_NB; k += 2)
+              if (ub + k + 1 <= 30) t[k] = sf_pkmin(t[k], t[k + 1]);
+            SF_VALU_FENCE();
+#pragma unroll
+            for (int k = 0; k < SF_HELP_NB; k += 2)
+              if (ub + k <= 30) { if (k & 2) accb = sf_pkmin(accb, t[k]); else acc = sf_pkmin(acc, t[k]); }
+          } else {
+#pragma unroll
+            for (int k = 0; k < SF_HELP_NB; k++) {
+              const int u = ub + k;
+              if (u <= 30) {
+                const uint32_t x = SHIFT ? w0[k] : ((w0[k] & 0xffffu) | (w1[k] & 0xffff0000u));  // (CB[1], C1N[2])
+                const uint32_t y = (w3[k] & 0xffffu) | (w2[k] & 0xffff0000u);  // (CB[1+u], C1N[u])
+                acc = sf_pkmin(acc, sf_pkadd(sf_pkmin(x, y), wt[k]));
+              }
             }
           }
         }
+        acc = sf_pkmin(acc, accb);
         gb = sf_lo(acc); g1 = sf_hi(acc);
       }
       eh = sfd_min(eh, gb + tau_out);
@@ -799,7 +871,10 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
   // final on the even diagonal; provisional (neighbour term still missing) on the odd one
   X.fML[FBASE(d) + i0] = (int16_t)(f > SF_FAST_THRESH ? SF_INF16 : f);
 #undef ROW
-#undef BNROW
+#undef ROWB_CI
+#undef ROWB_BN
+#undef CIROW
+#undef BNROWB
 }
 
 // minimum over the 64 lanes of a wave, returned in every lane.  DPP row operations + one readlane: no LDS
@@ -1230,19 +1305,31 @@ __device__ __forceinline__ void sf_trail_result(const SfTrail<NQ> &T, const int 
 }
 
 
+// the poison build's pattern for int16 entry x (see PZ below)
+__device__ __forceinline__ int16_t sf_poison16(const int poison, const int x) {
+  const int k = poison == 5 ? 1 + (int)(((uint32_t)x * 2654435761u) >> 30) : poison;
+  return (int16_t)(k == 1 ? -32768 : (k == 2 ? -28000 : (k == 3 ? 0 : 32767)));
+}
+
 // MG: the merged helper (narrow kernel, W < SF_HELP_MERGE_MAXW; the launcher picks the instantiation)
 // HC: every fold has its own hard constraint (cons_rows + seq * W, W characters) and / or Deigan pseudo-energies
 // (sc_rows + seq * W, dcal/mol per nucleotide): the constrained native windows of `-c` / `--react` (sf_fold_constrained)
-template <int NG, int WT, bool MG = false, bool HC = false>
+// PZ: the poison build (SCANFOLD_MFE_POISON, tests only): before every fold each LDS byte the fold has not written itself —
+// the whole fML area, the rolling tables with their mirror rows and cell lists, the constraint area — is filled with an
+// adversarial int16 pattern (poison = 1: -32768, 2: -28000, 3: 0, 4: 32767, 5: one of them per entry); the fold's own
+// initialisation then runs as in the product.  Energies and structures must not move (tests/test_gpu_paths.py,
+// tests/test_emul_kernels.py).
+template <int NG, int WT, bool MG = false, bool HC = false, bool PZ = false>
 __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_kernel(const uint8_t *__restrict__ seqs, int n, int Wrt,
                                                              const SfDevParams *__restrict__ D,
                                                              const SfFastParams *__restrict__ F,
+                                                             const SfFastRows *__restrict__ Rows,
                                                              int16_t *__restrict__ cg_all, int32_t *__restrict__ out,
                                                              int *__restrict__ ovf_cnt, int *__restrict__ ovf_list,
                                                              int trace_stride, char *__restrict__ db_out,
                                                              int *__restrict__ status, int *__restrict__ work_ctr,
                                                              const char *__restrict__ cons_rows,
-                                                             const int32_t *__restrict__ sc_rows) {
+                                                             const int32_t *__restrict__ sc_rows, int poison) {
   constexpr int NT = 2 * NG;
   constexpr bool FOLD = (NG == 256);  // W > 128: fML in the folded rectangle (see the file header)
   const int W = WT ? WT : Wrt;
@@ -1275,8 +1362,9 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
   int32_t *flag = (int32_t *)(smem + Lo.off_flag);
   uint8_t *S = (uint8_t *)(smem + Lo.off_S);
   X.S = S;
-  X.D = D; X.F = F; X.W = W; X.fold = FOLD; X.maxd = D->max_pair_dist;
+  X.D = D; X.F = F; X.R = Rows; X.W = W; X.fold = FOLD; X.maxd = D->max_pair_dist;
   constexpr bool MERGE = MG && SF_HELP_MERGE && (NG == 128);
+  constexpr bool TBLK = WT > 0 || (NG == 128 && !MG);  // rolling-row offsets from SfFastRows (see sf_fast_cell)
   X.bn_dup = (NG == 128);
   uint8_t *const cell_list = (uint8_t *)(smem + Lo.off_list);
   X.TAU = D->P.TerminalAU; X.MLbase = D->P.MLbase; X.MLclosing = D->P.MLclosing; X.MLintern = D->P.MLintern[1];
@@ -1303,9 +1391,6 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
     X.uNIN = uni;
     for (int x = tid; x < 128; x += NT) uni[x] = F->uni[x];
   }
-  // the rolling tables start out as "no structure": the guarded short-diagonal code reads rows no diagonal of the
-  // first fold has written yet (later folds find the previous fold's energies there, which is as good)
-  for (int x = tid; x < (Lo.off_tab - Lo.off_ci) / 2; x += NT) X.CI[x] = SF_INF16;  // incl. the mirror row and the cell lists
   // group and centre-based mapping inside the group: v = (tg + OFF) mod NG, cell i = v - d/2
   const int grp = SF_WAVE_UNIFORM(tid / NG);  // a wave lies in one group: keep d, row slots, loop limits scalar
   const int tg = tid - grp * NG;
@@ -1356,7 +1441,22 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
   while (seq < n) {
     const uint8_t *src = seqs + (size_t)seq * W;
     __syncthreads();
+    if (PZ) {
+      for (int x = tid; x < Lo.off_tab / 2; x += NT) ((int16_t *)smem)[x] = sf_poison16(poison, x);
+      if (HC) for (int x = tid; x < (Lo.total - Lo.off_hc) / 2; x += NT) ((int16_t *)(smem + Lo.off_hc))[x] = sf_poison16(poison, x);
+      __syncthreads();
+    }
     for (int x = tid; x < W; x += NT) S[x + 1] = sf_encode_nt(src[x]);
+    // The rolling tables (with their mirror rows and the cell lists) start every fold as "no structure".  The straight-line
+    // cell code of the short diagonals reads candidates of loop sizes that do not exist yet — rows no diagonal of this fold
+    // has written, up to 23 words past the end of a row — and charges them 32 767; the sum only stays "none" if what it
+    // finds is energy-sized.  Until round 4 the tables were initialised once per workgroup and later folds found the
+    // previous fold's energies there — as good, unless that fold had left the int16 range.  24 dword stores per thread
+    // and fold (0.05 % of a fold) make a fold's result a function of its own sequence only.
+#ifdef SF_EXP_NOREINIT
+    if (seq == (int)blockIdx.x)
+#endif
+    for (int x = tid; x < (Lo.off_tab - Lo.off_ci) / 4; x += NT) ((uint32_t *)X.CI)[x] = sf_pk(SF_INF16, SF_INF16);
     int fetched = 0;
     if (tid == 0) {
       S[0] = 0; S[W + 1] = 0; flag[0] = 0;
@@ -1451,14 +1551,14 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
       if (__ballot(valid)) {
         if (d0 < 8) sf_fast_cell<true, WT, SF_SEC_ALL, false, FOLD, 1>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
         else if (d0 < SF_FAST_TINY_D0) sf_fast_cell<true, WT, SF_SEC_ALL, false, FOLD, 5>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
-        else if (d0 < SF_FAST_CHUNK_D0) sf_fast_cell<false, WT, SF_SEC_ALL, true, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
-        else if (!split) sf_fast_cell<false, WT, SF_SEC_ALL, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
+        else if (d0 < SF_FAST_CHUNK_D0) sf_fast_cell<false, WT, SF_SEC_ALL, true, FOLD, SFD_MAXLOOP, TBLK>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
+        else if (!split) sf_fast_cell<false, WT, SF_SEC_ALL, false, FOLD, SFD_MAXLOOP, TBLK>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
         else if (!helper) {
-          if (SHARE) sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_DML | SF_SEC_PRE, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub, SFD_TURN + 1, dml_cut - 1);
+          if (SHARE) sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_DML | SF_SEC_PRE, false, FOLD, SFD_MAXLOOP, TBLK>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub, SFD_TURN + 1, dml_cut - 1);
           else if (DML2) {
             dec = sf_fast_dml2<WT>(X, d, tid & 63, i, valid);
-            sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_PRE, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
-          } else sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_DML | SF_SEC_PRE, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
+            sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_PRE, false, FOLD, SFD_MAXLOOP, TBLK>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
+          } else sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_DML | SF_SEC_PRE, false, FOLD, SFD_MAXLOOP, TBLK>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
         } else if (MERGE) {
           // Merged helper (W <= 128).  ONE helper wave serves both diagonals of the step: it works on the list of the
           // cells of d0 and d0+1 that can pair (build_list above; 3 of 8 cells, so ordinary sequences fit wave 1's 64
@@ -1478,7 +1578,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
             const int sd1 = sd0 + 1 >= SF_FAST_NR ? 0 : sd0 + 1;
             SfFastCtx Xh = X;
             Xh.BN = X.BN + 2 * g * (W - 4);
-            sf_fast_cell<false, WT, SF_SEC_HELP, false, FOLD>(Xh, d0 + g, iC, vC, s2, sd0, H, ovf, false, fnb, fpart, dec, eh, e0, dprev, pub);
+            sf_fast_cell<false, WT, SF_SEC_HELP, false, FOLD, SFD_MAXLOOP, TBLK>(Xh, d0 + g, iC, vC, s2, sd0, H, ovf, false, fnb, fpart, dec, eh, e0, dprev, pub);
             if (vC) X.BN[2 * ((g ? sd1 : sd0) * (W - 4) + iC - 1)] = (int16_t)sfd_min(eh, 32000);
           }
         } else {
@@ -1486,13 +1586,13 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
           // step, and rewritten by nobody but the cell's own lane): eh in the CB half of its word, its part of the
           // multiloop split in its CI entry
           if (SHARE) {
-            sf_fast_cell<false, WT, SF_SEC_HELP | SF_SEC_DML, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub, dml_cut);
+            sf_fast_cell<false, WT, SF_SEC_HELP | SF_SEC_DML, false, FOLD, SFD_MAXLOOP, TBLK>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub, dml_cut);
             if (valid) {
               X.BN[2 * (slotd * (W - 4) + i - 1)] = (int16_t)sfd_min(eh, 32000);
               X.CI[slotd * (W - 4) + i - 1] = (int16_t)sfd_min(dec, 32000);
             }
           } else {
-            sf_fast_cell<false, WT, SF_SEC_HELP, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
+            sf_fast_cell<false, WT, SF_SEC_HELP, false, FOLD, SFD_MAXLOOP, TBLK>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
             if (valid) X.BN[2 * (slotd * (W - 4) + i - 1)] = (int16_t)sfd_min(eh, 32000);
           }
         }
@@ -1507,7 +1607,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
             eh = X.BN[2 * (slotd * (W - 4) + i - 1)];
             if (SHARE) dec = sfd_min(dec, (int)X.CI[slotd * (W - 4) + i - 1]);
           }
-          sf_fast_cell<false, WT, SF_SEC_FIN | SF_SEC_POST, false, FOLD>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
+          sf_fast_cell<false, WT, SF_SEC_FIN | SF_SEC_POST, false, FOLD, SFD_MAXLOOP, TBLK>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
         }
       }
       __syncthreads();
@@ -1570,23 +1670,27 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
 #undef FLEN
 }
 
+template <int NG, int WT, bool MG = false, bool HC = false, bool PZ = false>
+static inline hipError_t sf_fast_configure_one() {
+  return hipFuncSetAttribute((const void *)sf_mfe_fast_kernel<NG, WT, MG, HC, PZ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
 static inline hipError_t sf_fast_configure() {
-  hipError_t e = hipFuncSetAttribute((const void *)sf_mfe_fast_kernel<128, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute((const void *)sf_mfe_fast_kernel<128, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute((const void *)sf_mfe_fast_kernel<128, 120>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute((const void *)sf_mfe_fast_kernel<256, 200>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute((const void *)sf_mfe_fast_kernel<256, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e != hipSuccess) return e;
+  hipError_t e;
+  if ((e = sf_fast_configure_one<128, 0>()) != hipSuccess) return e;
+  if ((e = sf_fast_configure_one<128, 0, true>()) != hipSuccess) return e;
+  if ((e = sf_fast_configure_one<128, 120>()) != hipSuccess) return e;
+  if ((e = sf_fast_configure_one<256, 200>()) != hipSuccess) return e;
+  if ((e = sf_fast_configure_one<256, 0>()) != hipSuccess) return e;
   // the instantiations for constrained folds (generic widths only)
-  e = hipFuncSetAttribute((const void *)sf_mfe_fast_kernel<128, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e != hipSuccess) return e;
-  e = hipFuncSetAttribute((const void *)sf_mfe_fast_kernel<128, 0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (e != hipSuccess) return e;
-  return hipFuncSetAttribute((const void *)sf_mfe_fast_kernel<256, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if ((e = sf_fast_configure_one<128, 0, false, true>()) != hipSuccess) return e;
+  if ((e = sf_fast_configure_one<128, 0, true, true>()) != hipSuccess) return e;
+  if ((e = sf_fast_configure_one<256, 0, false, true>()) != hipSuccess) return e;
+  // the poison builds (SCANFOLD_MFE_POISON: tests only)
+  if ((e = sf_fast_configure_one<128, 0, false, false, true>()) != hipSuccess) return e;
+  if ((e = sf_fast_configure_one<128, 0, true, false, true>()) != hipSuccess) return e;
+  if ((e = sf_fast_configure_one<128, 120, false, false, true>()) != hipSuccess) return e;
+  if ((e = sf_fast_configure_one<256, 200, false, false, true>()) != hipSuccess) return e;
+  return sf_fast_configure_one<256, 0, false, false, true>();
 }
 
 // grid / LDS / scratch for n folds of W nt on a chip with n_cu CUs
@@ -1612,20 +1716,27 @@ static inline void sf_fast_geometry(int W, int n_cu, int n, int *grid, int *thre
 // W = 120 is ScanFold's default window (ScanFold-Scan.py:37) and W = 200 is BASELINE config 5: they get
 // instantiations with the width folded in (less scalar index arithmetic, fewer spills); any other width runs
 // the generic instantiation
+template <bool PZ, typename... A>
+static inline void sf_fast_launch_pz(int grid, int threads, size_t lds, hipStream_t st, const uint8_t *seqs, int n, int W,
+                                     A... args) {
+  if (threads == 256 && W == 120) SF_LAUNCH((sf_mfe_fast_kernel<128, 120, false, false, PZ>), grid, 256, lds, st, seqs, n, W, args...);
+  else if (threads == 256 && W < SF_HELP_MERGE_MAXW && SF_HELP_MERGE) SF_LAUNCH((sf_mfe_fast_kernel<128, 0, true, false, PZ>), grid, 256, lds, st, seqs, n, W, args...);
+  else if (threads == 256) SF_LAUNCH((sf_mfe_fast_kernel<128, 0, false, false, PZ>), grid, 256, lds, st, seqs, n, W, args...);
+  else if (W == 200) SF_LAUNCH((sf_mfe_fast_kernel<256, 200, false, false, PZ>), grid, 512, lds, st, seqs, n, W, args...);
+  else SF_LAUNCH((sf_mfe_fast_kernel<256, 0, false, false, PZ>), grid, 512, lds, st, seqs, n, W, args...);
+}
+// poison != 0: the poison builds (tests only); the last kernel argument
 template <typename... A>
-static inline void sf_fast_launch(int grid, int threads, size_t lds, hipStream_t st, const uint8_t *seqs, int n, int W,
+static inline void sf_fast_launch(int poison, int grid, int threads, size_t lds, hipStream_t st, const uint8_t *seqs, int n, int W,
                                   A... args) {
-  if (threads == 256 && W == 120) SF_LAUNCH((sf_mfe_fast_kernel<128, 120>), grid, 256, lds, st, seqs, n, W, args...);
-  else if (threads == 256 && W < SF_HELP_MERGE_MAXW && SF_HELP_MERGE) SF_LAUNCH((sf_mfe_fast_kernel<128, 0, true>), grid, 256, lds, st, seqs, n, W, args...);
-  else if (threads == 256) SF_LAUNCH((sf_mfe_fast_kernel<128, 0>), grid, 256, lds, st, seqs, n, W, args...);
-  else if (W == 200) SF_LAUNCH((sf_mfe_fast_kernel<256, 200>), grid, 512, lds, st, seqs, n, W, args...);
-  else SF_LAUNCH((sf_mfe_fast_kernel<256, 0>), grid, 512, lds, st, seqs, n, W, args...);
+  if (poison) sf_fast_launch_pz<true>(grid, threads, lds, st, seqs, n, W, args..., poison);
+  else sf_fast_launch_pz<false>(grid, threads, lds, st, seqs, n, W, args..., 0);
 }
 // constrained folds (per-fold hard constraint / Deigan pseudo-energies; every fold traced)
 template <typename... A>
 static inline void sf_fast_launch_hc(int grid, int threads, size_t lds, hipStream_t st, const uint8_t *seqs, int n, int W,
                                      A... args) {
-  if (threads == 256 && W < SF_HELP_MERGE_MAXW && SF_HELP_MERGE) SF_LAUNCH((sf_mfe_fast_kernel<128, 0, true, true>), grid, 256, lds, st, seqs, n, W, args...);
-  else if (threads == 256) SF_LAUNCH((sf_mfe_fast_kernel<128, 0, false, true>), grid, 256, lds, st, seqs, n, W, args...);
-  else SF_LAUNCH((sf_mfe_fast_kernel<256, 0, false, true>), grid, 512, lds, st, seqs, n, W, args...);
+  if (threads == 256 && W < SF_HELP_MERGE_MAXW && SF_HELP_MERGE) SF_LAUNCH((sf_mfe_fast_kernel<128, 0, true, true>), grid, 256, lds, st, seqs, n, W, args..., 0);
+  else if (threads == 256) SF_LAUNCH((sf_mfe_fast_kernel<128, 0, false, true>), grid, 256, lds, st, seqs, n, W, args..., 0);
+  else SF_LAUNCH((sf_mfe_fast_kernel<256, 0, false, true>), grid, 512, lds, st, seqs, n, W, args..., 0);
 }

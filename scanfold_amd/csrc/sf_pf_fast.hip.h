@@ -25,14 +25,25 @@ struct SfPfTabs {
   double *QB, *QBI, *QB1N, *QBB, *QM, *QM1, *OB, *OBI, *OB1N, *OBB, *OBW, *A0, *A1;
 };
 
-template <int NT, int WT>
+// HC: fold k has its own hard constraint, W characters at cons_rows + k * row_stride * W (fc.hc_add_from_db before fc.pf(),
+// ScanFold-Scan.py:405-412).  As in the LDS kernels the constraint acts where a cell's OWN pair type is made (inside, the
+// two exterior sums, outside): a forbidden pair has qb = 0 and drops out of every sum that reads it; the types of enclosed /
+// enclosing pairs in the special-loop look-ups stay sequence-only.  W <= 250 (partners are bytes); a bracket pair of
+// non-complementary bases never comes here (the host routes such batches to sf_pf_kernel).  Until round 4 a constrained
+// scan at 120 < W <= 256 ran its partition functions on sf_pf_kernel — O(W^2 L^2) per fold, ~90 x slower.
+template <int NT, int WT, bool HC = false>
 __global__ __launch_bounds__(NT, 2) void sf_pf_fast_kernel(const uint8_t *__restrict__ seqs, int n, int row_stride, int Wrt,
                                                         const SfDevParams *__restrict__ D,
                                                         const SfDevParamsPF *__restrict__ X,
                                                         double *__restrict__ scratch, double *__restrict__ ens_dG,
                                                         double *__restrict__ mean_bp_dist, char *__restrict__ centroid,
-                                                        double *__restrict__ centroid_dist) {
+                                                        double *__restrict__ centroid_dist,
+                                                        const char *__restrict__ cons_rows, int *__restrict__ status) {
   __shared__ uint8_t S[SF_PFF_MAXW + 2];
+  __shared__ char hcC[HC ? SF_PFF_MAXW + 2 : 1];
+  __shared__ uint8_t hcP[HC ? SF_PFF_MAXW + 2 : 1], hcE[HC ? SF_PFF_MAXW + 2 : 1];
+  SfHc8 hc;
+  hc.c = (HC && cons_rows) ? hcC : nullptr; hc.partner = hcP; hc.encl = hcE;
   __shared__ double q5[SF_PFF_MAXW + 2];
   __shared__ double q3[SF_PFF_MAXW + 3];
   __shared__ double red[8];
@@ -49,6 +60,9 @@ __global__ __launch_bounds__(NT, 2) void sf_pf_fast_kernel(const uint8_t *__rest
   }
 // triangular, diagonal-major: diagonal d holds the cells i = 1..W-d
 #define PT(tab, d, i) tab[(d)*W - ((d) * ((d)-1)) / 2 + (i)-1]
+// the pair type of a cell's OWN pair (a, b): sequence, max_bp_span and — HC — the fold's constraint
+#define OWNT(Dp, a, b) (HC ? sf_hc_type8(hc, ((b) - (a) <= (Dp)->max_pair_dist ? (Dp)->pair[S[a]][S[b]] : 0), (a), (b), (b) - (a) <= (Dp)->max_pair_dist) \
+                           : ((b) - (a) <= (Dp)->max_pair_dist ? (Dp)->pair[S[a]][S[b]] : 0))
   const double *mlb = X->mlbase_pow;
   const int OFF = (((W + 1) >> 1) - 32 + NT) & (NT - 1);
   const int v = (tid + OFF) & (NT - 1);
@@ -59,6 +73,11 @@ __global__ __launch_bounds__(NT, 2) void sf_pf_fast_kernel(const uint8_t *__rest
     __syncthreads();
     for (int x = tid; x < W; x += NT) S[x + 1] = sf_encode_nt(src[x]);
     if (tid == 0) { S[0] = 0; S[W + 1] = 0; }
+    if (HC && cons_rows) {
+      for (int x = tid; x < W; x += NT) hcC[x + 1] = cons_rows[(size_t)k * row_stride * W + x];
+      __syncthreads();
+      if (tid == 0 && sf_hc_parse8(W, hcC, hcP, hcE)) atomicOr(status, 2);  // unbalanced: reported; runs with what matched
+    }
     for (size_t x = tid; x < (size_t)4 * W && x < TS; x += NT) {
       T.QB[x] = 0.0; T.QBI[x] = 0.0; T.QB1N[x] = 0.0; T.QBB[x] = 0.0; T.QM[x] = 0.0; T.QM1[x] = 0.0;
     }
@@ -80,7 +99,7 @@ __global__ __launch_bounds__(NT, 2) void sf_pf_fast_kernel(const uint8_t *__rest
       const bool valid = (i >= 1) && (j <= W);
       if (valid) {
         const int umax = G ? sfd_min(SFD_MAXLOOP, d - 2 - (SFD_TURN + 1)) : SFD_MAXLOOP;
-        const int type = j - i <= Dc->max_pair_dist ? Dc->pair[S[i]][S[j]] : 0;
+        const int type = OWNT(Dc, i, j);
         const int si1 = S[i + 1], sj1 = S[j - 1];
         // generic interior sums of this cell from those of the enclosed cell
 #pragma unroll
@@ -167,7 +186,7 @@ __global__ __launch_bounds__(NT, 2) void sf_pf_fast_kernel(const uint8_t *__rest
       double val = 0.0;
       const int i = tid + 1;
       if (i + SFD_TURN + 1 <= j) {
-        const int type = j - i <= D->max_pair_dist ? D->pair[S[i]][S[j]] : 0;
+        const int type = OWNT(D, i, j);
         if (type) val = q5[i - 1] * PT(T.QB, j - i, i) * sfx_extloop(X, type, i > 1 ? S[i - 1] : -1, j < W ? S[j + 1] : -1);
       }
       val = sf_block_sum(val, red);
@@ -178,7 +197,7 @@ __global__ __launch_bounds__(NT, 2) void sf_pf_fast_kernel(const uint8_t *__rest
       double val = 0.0;
       const int j = tid + 1;
       if (j <= W && i + SFD_TURN + 1 <= j) {
-        const int type = j - i <= D->max_pair_dist ? D->pair[S[i]][S[j]] : 0;
+        const int type = OWNT(D, i, j);
         if (type) val = PT(T.QB, j - i, i) * sfx_extloop(X, type, i > 1 ? S[i - 1] : -1, j < W ? S[j + 1] : -1) * q3[j + 1];
       }
       val = sf_block_sum(val, red);
@@ -246,7 +265,7 @@ __global__ __launch_bounds__(NT, 2) void sf_pf_fast_kernel(const uint8_t *__rest
         }
         PT(T.A0, d, i) = a0;
         PT(T.A1, d, i) = a1;
-        const int type = j - i <= Dc->max_pair_dist ? Dc->pair[S[i]][S[j]] : 0;
+        const int type = OWNT(Dc, i, j);
         const double qbij = PT(T.QB, d, i);
         double o = 0.0;
         if (type && qbij != 0.0) {
@@ -370,12 +389,20 @@ __global__ __launch_bounds__(NT, 2) void sf_pf_fast_kernel(const uint8_t *__rest
     }
   }
 #undef PT
+#undef OWNT
 }
 
 template <typename... A>
 static inline void sf_pf_fast_launch(int grid, int W, hipStream_t st, A... args) {
-  if (W == 120) SF_LAUNCH((sf_pf_fast_kernel<128, 120>), grid, 128, 0, st, args...);
-  else if (W <= 128) SF_LAUNCH((sf_pf_fast_kernel<128, 0>), grid, 128, 0, st, args...);
-  else if (W == 200) SF_LAUNCH((sf_pf_fast_kernel<256, 200>), grid, 256, 0, st, args...);
-  else SF_LAUNCH((sf_pf_fast_kernel<256, 0>), grid, 256, 0, st, args...);
+  if (W == 120) SF_LAUNCH((sf_pf_fast_kernel<128, 120>), grid, 128, 0, st, args..., (const char *)nullptr, (int *)nullptr);
+  else if (W <= 128) SF_LAUNCH((sf_pf_fast_kernel<128, 0>), grid, 128, 0, st, args..., (const char *)nullptr, (int *)nullptr);
+  else if (W == 200) SF_LAUNCH((sf_pf_fast_kernel<256, 200>), grid, 256, 0, st, args..., (const char *)nullptr, (int *)nullptr);
+  else SF_LAUNCH((sf_pf_fast_kernel<256, 0>), grid, 256, 0, st, args..., (const char *)nullptr, (int *)nullptr);
+}
+// constrained folds (a constraint row per fold); W <= 250
+#define SF_PFF_HC_MAXW 250
+template <typename... A>
+static inline void sf_pf_fast_launch_hc(int grid, int W, hipStream_t st, A... args) {
+  if (W <= 128) SF_LAUNCH((sf_pf_fast_kernel<128, 0, true>), grid, 128, 0, st, args...);
+  else SF_LAUNCH((sf_pf_fast_kernel<256, 0, true>), grid, 256, 0, st, args...);
 }

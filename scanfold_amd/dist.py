@@ -116,6 +116,20 @@ def unpack_rows(buf, n):
     return rows
 
 
+def any_rank_failed(failed_here, world, device=None):
+    """One int32 all-reduce (MAX) of "my shard failed": True on every rank if it did on any.  Called by every rank before
+    the gather, so that a rank-local error cannot leave the others blocked in the collective."""
+    if world == 1:
+        return bool(failed_here)
+    import torch
+    import torch.distributed as dist
+    flag = torch.tensor([1 if failed_here else 0], dtype=torch.int32)
+    if device is not None:
+        flag = flag.to(device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    return bool(int(flag.item()))
+
+
 def gather_rows(rows, n_items, rank, world, W, device=None, want=True):
     """Every rank hands in the TSV rows of ITS window range (formatted where they were computed); ONE all-gather of
     fixed-size row slots returns all n_items rows in window order (want=False: None — a rank that does not write).

@@ -145,25 +145,49 @@ def _engine_chunks(work, lo, hi, chunk=None, threaded=True):
             yield w0, work(w0, nw)
         return
     q = queue.Queue(maxsize=2)
+    stop = threading.Event()
+
+    def put(item):
+        # (bounded queue: give up when the consumer has gone away, so that the thread can end)
+        while not stop.is_set():
+            try:
+                q.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                pass
+        return False
 
     def produce():
         try:
             for w0, nw in bounds:
-                q.put((w0, work(w0, nw)))
+                if stop.is_set() or not put((w0, work(w0, nw))):
+                    return
         except BaseException as e:  # hand the error to the consumer
-            q.put((None, e))
-        q.put((None, None))
+            put((None, e))
+            return
+        put((None, None))
 
     th = threading.Thread(target=produce, daemon=True)
     th.start()
-    while True:
-        w0, res = q.get()
-        if w0 is None:
-            th.join()
-            if res is not None:
-                raise res
-            return
-        yield w0, res
+    try:
+        while True:
+            w0, res = q.get()
+            if w0 is None:
+                if res is not None:
+                    raise res
+                return
+            yield w0, res
+    finally:
+        # The consumer is done — normally, or because formatting raised / the generator was closed mid-way.  The library is
+        # not re-entrant: nobody may call into it (e.g. to restore the temperature) while the helper thread is still inside
+        # work().  Tell it to stop, make room in the queue, and wait for it.
+        stop.set()
+        while th.is_alive():
+            try:
+                q.get_nowait()
+            except queue.Empty:
+                pass
+            th.join(timeout=0.05)
 
 
 def read_constraints(path, seq_len):
@@ -303,7 +327,21 @@ def scan_record_sharded(seq, W, step, r, shuffle_type, temperature, eng, seed, r
     from . import dist as sdist
     n_win = len(window_starts(len(seq), W, step))
     lo, hi = sdist.shard_range(n_win, rank, world)
-    rows = scan_record(seq, W, step, r, shuffle_type, temperature, eng, seed=seed, windows=(lo, hi), **kw)
+    # A failure that only one rank sees (an unbalanced constraint in ITS windows, a row that does not fit its gather slot)
+    # must not leave the others waiting in the collective: every rank reports how its shard went, one tiny all-reduce, and
+    # either everybody gathers or everybody raises.
+    rows, err = None, None
+    try:
+        rows = scan_record(seq, W, step, r, shuffle_type, temperature, eng, seed=seed, windows=(lo, hi), **kw)
+        sdist.pack_rows(rows, len(rows), sdist.row_slot_width(W))  # (raises if a row is too long for its slot)
+    except Exception as e:  # noqa: BLE001 — re-raised below, on every rank
+        err = e
+    failed = sdist.any_rank_failed(err is not None, world, device=device)
+    if failed:
+        if err is not None:
+            raise err
+        raise RuntimeError("rank %d: another rank failed while scanning its windows of this record (its own message "
+                           "is on that rank's stderr); nothing was gathered" % rank)
     return sdist.gather_rows(rows, n_win, rank, world, W, device=device, want=(rank == 0))
 
 

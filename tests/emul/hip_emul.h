@@ -171,6 +171,7 @@ inline T atomicOr(T *p, T v) { T o = *p; *p = o | v; return o; }
 #define SF_WAVE_UNIFORM(x) (x)
 #define SF_SCHED_GROUP(mask, n) ((void)0)
 #define SF_SCHED_FENCE() ((void)0)
+#define SF_VALU_FENCE() ((void)0)
 template <class T> static inline const T *sf_const_base(const T *p) { return p; }
 #define SF_PIN(x) ((void)0)
 #define SF_LANE_READ(v, l) __shfl((v), (l))

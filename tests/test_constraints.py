@@ -133,6 +133,30 @@ def test_constrained_kernels_follow_the_oracle(emul, oracle):
         oracle.set_constraint(None, None)
 
 
+def test_constrained_partition_function_above_120_uses_the_device_table_kernel(emul, oracle):
+    """120 < W <= 250: the constrained partition function runs on sf_pf_fast_kernel's HC instantiation (kernel mode 0) —
+    until round 4 it fell back to sf_pf_kernel, ~90 x slower per fold.  Both modes equal each other and the oracle."""
+    emul.load_params(params.default_params())
+    rng = np.random.default_rng(8)
+    try:
+        for W in (121, 137):
+            seqs = [rseq(rng, W) for _ in range(2)]
+            cons = [canonical_constraint(rng, s, 4) for s in seqs]
+            emul.set_kernel_mode(1)
+            r1 = emul.fold_constrained(seqs, cons, mfe=False)
+            emul.set_kernel_mode(0)
+            r = emul.fold_constrained(seqs, cons, mfe=False)
+            assert r["centroid"] == r1["centroid"] and np.abs(np.asarray(r["dG"]) - np.asarray(r1["dG"])).max() < 1e-9
+            for k in range(2):
+                oracle.set_constraint(cons[k], None)
+                o = oracle.pf(seqs[k])
+                assert o["centroid"] == r["centroid"][k]
+                assert abs(o["dG"] - r["dG"][k]) < 1e-9 and abs(o["mean_bp_dist"] - r["mean_bp_dist"][k]) < 1e-9
+    finally:
+        emul.set_kernel_mode(0)
+        oracle.set_constraint(None, None)
+
+
 def test_rna_facade_constraints_and_shape(emul, oracle, monkeypatch):
     from scanfold_amd import RNA
     emul.load_params(params.default_params())

@@ -180,3 +180,53 @@ def test_row_gather_over_gloo_ragged_and_empty_shards(tmp_path, nproc, n_win):
     assert out.returncode == 0, out.stderr[-2000:]
     for rank in range(nproc):
         assert "RANK%d_ROWS_OK=True" % rank in out.stdout, out.stdout + out.stderr[-1000:]
+
+
+def test_cli_gpus_2_rank_local_constraint_error_fails_on_every_rank_instead_of_hanging(tmp_path):
+    """A constraint whose brackets are unbalanced only in windows of the SECOND rank's shard: that rank raises before the
+    gather.  Every rank must learn it (one all-reduce of a status flag) and end with an error — the other rank must not sit
+    in all_gather_into_tensor until the collective times out."""
+    from emul_engine import build, EMUL_LIB
+    build()
+    seq = "".join("ACGU"[k] for k in np.random.default_rng(8).integers(0, 4, 83))
+    fa = tmp_path / "in.fa"
+    _write_fasta(fa, seq)
+    line = ["."] * len(seq)
+    line[70], line[80] = "(", ")"   # complete in the last windows only ...
+    line[60] = "("                  # ... and an opening bracket that never closes inside the windows that hold it
+    cons = tmp_path / "cons.txt"
+    cons.write_text(">rec1\n" + seq + "\n" + "".join(line) + "\n")
+    env = {"SCANFOLD_LIB_PATH": EMUL_LIB, "SCANFOLD_DEVICE": "0", "SCANFOLD_DIST_BACKEND": "gloo"}
+    b = _run_cli(["-i", str(fa), "-w", "30", "-s", "6", "-r", "2", "-type", "di", "--seed", "4", "-c", str(cons), "--gpus", "2",
+                  "-o", str(tmp_path / "two.tsv")], env, timeout=240)
+    assert b.returncode != 0
+    assert "unbalanced" in b.stderr and "another rank failed" in b.stderr, b.stderr[-3000:]
+
+
+def test_engine_chunks_joins_its_helper_thread_before_the_caller_touches_the_library_again():
+    """scan._engine_chunks: when the consumer stops early (formatting raised, generator closed), the helper thread — the
+    only one allowed inside the non-reentrant library while it lives — must have left work() before control returns."""
+    import threading
+    import time
+    from scanfold_amd import scan as scanmod
+    inside, log = threading.Event(), []
+
+    def work(w0, nw):
+        inside.set()
+        time.sleep(0.15)
+        log.append(("done", w0))
+        inside.clear()
+        return {"ens_div": [0] * nw}
+
+    gen = scanmod._engine_chunks(work, 0, 50, chunk=5, threaded=True)
+    first = next(gen)
+    assert first[0] == 0
+    gen.close()  # what a raising consumer does to the generator
+    assert not inside.is_set()
+    n_done = len(log)
+    time.sleep(0.4)
+    assert len(log) == n_done and n_done <= 4  # nothing ran after close(); the remaining chunks were never started
+    with pytest.raises(RuntimeError, match="boom"):
+        for w0, _ in scanmod._engine_chunks(work, 0, 50, chunk=5, threaded=True):
+            raise RuntimeError("boom")
+    assert not inside.is_set()

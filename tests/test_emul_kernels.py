@@ -248,3 +248,24 @@ def test_two_resident_models_switch_without_reload(emul, oracle):
         emul.set_max_bp_span(0); oracle.set_max_bp_span(0)
         oracle.set_params(base)
         emul.load_params(base)
+
+
+def test_poisoned_lds_slack_does_not_move_an_energy_emulated(emul, oracle, monkeypatch):
+    """SCANFOLD_MFE_POISON (sf_mfe_fast.hip.h, PZ): before every fold each LDS byte the fold has not written itself holds
+    -32768 / -28000 / 0 / 32767 / a mix.  The short-diagonal cell code over-reads rows no diagonal has written yet and the
+    slack behind them; energies and tracebacks must equal the oracle under every pattern — on workgroups that fold several
+    sequences in a row (the emulated device has few CUs), at one width per instantiation.  The GPU twin of this test is
+    tests/test_gpu_paths.py::test_poisoned_lds_slack_does_not_move_an_energy."""
+    emul.load_params(params.default_params())
+    rng = np.random.default_rng(5)
+    cases = [(W, random_seqs(rng, n, W)) for W, n in ((16, 12), (40, 10), (77, 8), (117, 6), (120, 6), (128, 5), (131, 3), (200, 2))]
+    refs = [(oracle.mfe_batch(arr), [oracle.mfe(bytes(r).decode()) for r in arr[:2]]) for _, arr in cases]
+    for pattern in ("1", "2", "3", "4", "5"):
+        monkeypatch.setenv("SCANFOLD_MFE_POISON", pattern)
+        for (W, arr), (ref, traces) in zip(cases, refs):
+            assert (emul.mfe_batch(arr) == ref).all(), (pattern, W)
+            e, db = emul.mfe_trace_batch(arr[:2])
+            assert [(db[k], e[k]) for k in range(2)] == traces, (pattern, W)
+    monkeypatch.delenv("SCANFOLD_MFE_POISON")
+    for (W, arr), (ref, _) in zip(cases, refs):
+        assert (emul.mfe_batch(arr) == ref).all(), W

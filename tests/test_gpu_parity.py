@@ -467,7 +467,8 @@ def test_constrained_native_folds_match_oracle(gpu_engine, oracle):
     rng = np.random.default_rng(77)
     try:
         for W, n, use_sc, canon in ((120, 300, False, True), (120, 300, False, False), (120, 60, True, True), (45, 64, True, True),
-                                    (100, 40, True, False), (200, 12, False, True)):
+                                    (100, 40, True, False), (200, 12, False, True), (160, 12, True, True), (250, 6, False, True),
+                                    (121, 12, False, True)):  # 120 < W <= 250: sf_pf_fast_kernel's HC instantiation
             seqs = [rseq(rng, W) for _ in range(n)]
             cons = [canonical_constraint(rng, s, 4) for s in seqs] if canon else [random_constraint(rng, W, 4) for _ in range(n)]
             sc = rng.integers(-60, 40, (n, W)).astype(np.int32) if use_sc else None

@@ -1,0 +1,154 @@
+"""Paths of the product that had only run in builder-side scripts, now under the driver's `-m gpu` run:
+
+* the RCCL exchange — `bench.py` as ONE rank under torch.distributed.run with SCANFOLD_BENCH_FORCE_DIST=1: process group on
+  the "nccl" backend, record packing on the device, all_gather_into_tensor, un-padding, and the oracle check on what the
+  gather delivered (north_star: "a single RCCL gather over xGMI at the end");
+* a stretch of 120 x N inside a transcript through scan_record on the HIP engine (ScanFold-Scan.py:374-380: the literal
+  row; the device dinucleotide shuffle of a one-symbol window; the partition function of a window that cannot pair);
+* `-type mono` through the command line against the shuffle oracle on BASELINE configs 1 and 2 (ScanFold-Scan.py:273-274);
+* the slack the short-diagonal cell code over-reads, poisoned (SCANFOLD_MFE_POISON): energies must not move.
+Nothing here reads /root/reference."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from scanfold_amd import _lib
+from scanfold_amd import scan as scanmod
+from conftest import random_seqs
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def ascii_rows(codes):
+    return np.frombuffer(b"NACGU", dtype=np.uint8)[codes]
+
+
+def synth_transcript(L, seed):
+    return "".join("ACGU"[k] for k in np.random.default_rng(seed).integers(0, 4, L))
+
+
+def expected_rows(oracle, seq, W, step, r, kind, seed):
+    """The TSV rows the reference's loop would write for `seq` with the oracle as its RNA module and the shuffle oracle as its
+    scramble(): every window's r+1 energies, structure, centroid, ensemble diversity (one OpenMP thread per window)."""
+    starts = scanmod.window_starts(len(seq), W, step)
+    rows = ascii_rows(oracle.shuffle_windows(seq, W, step, 0, len(starts), r, kind, seed))
+    ref = oracle.scan_windows(rows, len(starts), r)
+    return scanmod.rows_from_results(seq, starts, W, r, 37, ref["energies"], ref["structure"], ref["centroid"], ref["ens_div"])
+
+
+def test_bench_single_rank_over_rccl_cfg2():
+    """bench.py --config cfg2 as one rank under torch.distributed.run: init_process_group("nccl"), pack_records on the device,
+    all_gather_into_tensor, merge_shards — and 64 windows of what the gather delivered == oracle."""
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0",
+           "--no-live-counters", "--no-cpu-baseline", "--config", "cfg2"]
+    env = dict(os.environ, SCANFOLD_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["config"]["windows"] == 989 and out["config"]["mfe_folds_per_step"] == 30659
+    gc = out["gather_check"]
+    assert gc is not None and gc["backend"] == "nccl" and gc["ranks"] == 1 and gc["windows"] == 989
+    assert gc["rank0_shard_equals_its_device_tensors"] is True
+    assert out["verified_windows"] == 64 and out["verified_mismatches"] == 0 and out["device_status"] == 0
+    assert "gathered records" in out["verified_against"]
+    assert out["roofline"]["launches"] == 1 and out["roofline"]["folds_per_launch"] == 30659
+
+
+def test_all_n_stretch_inside_a_transcript(gpu_engine, oracle):
+    """ScanFold-Scan.py:374-380 on the engine: windows that are 120 x N get the literal row, the windows that overlap the
+    stretch partly — N folds as a non-pairing nucleotide and is a fifth symbol for the device dinucleotide shuffle — equal
+    the oracle-built rows, for both shuffle types."""
+    rng = np.random.default_rng(31)
+    left = "".join("ACGU"[k] for k in rng.integers(0, 4, 310))
+    right = "".join("ACGT"[k] for k in rng.integers(0, 4, 290))  # T: transcribed in the output column
+    seq = left + "N" * 150 + right
+    W, step, r = 120, 10, 12
+    literal = "\t37\t0\t#DIV/0\t0\t0\t" + "N" * 120 + "\t" + "." * 120 + "\t" + "." * 120 + "\n"
+    for name, kind in (("di", _lib.SHUFFLE_DI), ("mono", _lib.SHUFFLE_MONO)):
+        got = scanmod.scan_record(seq, W, step, r, name, 37, gpu_engine, seed=9)
+        exp = expected_rows(oracle, seq, W, step, r, kind, 9)
+        assert len(got) == len(scanmod.window_starts(len(seq), W, step)) == 64
+        all_n = [k for k, i in enumerate(scanmod.window_starts(len(seq), W, step)) if seq[i:i + W] == "N" * W]
+        assert all_n == [31, 32, 33, 34]
+        for k in all_n:
+            assert got[k] == "%d\t%d" % (k * step + 1, k * step + W) + literal
+        assert got == exp
+        # the engine's raw output for an all-N window: energy 0 for the native and every shuffle, no pair anywhere
+        res = gpu_engine.scan(seq, W, step, 31, 4, r, kind, 9)
+        assert (res["energies"] == 0).all() and res["structure"] == ["." * W] * 4 == res["centroid"]
+        assert np.abs(res["ens_div"]).max() < 1e-12
+
+
+@pytest.mark.parametrize("cfg", [(1000, 1, 40, 10, 23), (10000, 2, 10, 30, 989)])
+def test_cli_mono_shuffles_cfg1_cfg2_against_the_shuffle_oracle(gpu_engine, oracle, tmp_path, cfg):
+    """`-type mono` (the reference's default, ScanFold-Scan.py:43,273-274) through the command line on BASELINE configs 1 and
+    2: the file == header + the rows built from the oracle on the shuffle oracle's mononucleotide shuffles, byte for byte."""
+    L, tseed, step, r, n_win = cfg
+    seq = synth_transcript(L, tseed)
+    fa = tmp_path / "in.fa"
+    with open(fa, "w") as f:
+        f.write(">cfg synthetic\n")
+        for k in range(0, len(seq), 70):
+            f.write(seq[k:k + 70] + "\n")
+    out = tmp_path / "out.tsv"
+    assert scanmod.main(["-i", str(fa), "-w", "120", "-s", str(step), "-r", str(r), "-type", "mono", "--seed", "21",
+                         "-o", str(out)]) == 0
+    exp = expected_rows(oracle, seq, 120, step, r, _lib.SHUFFLE_MONO, 21)
+    assert len(exp) == n_win
+    assert out.read_text() == scanmod.header_line("cfg") + "".join(exp)
+    # and the shuffles behind those rows are permutations of their window that differ from the dinucleotide ones
+    mono = gpu_engine.shuffle_windows(seq, 120, step, 0, 3, r, _lib.SHUFFLE_MONO, 21)
+    di = gpu_engine.shuffle_windows(seq, 120, step, 0, 3, r, _lib.SHUFFLE_DI, 21)
+    assert (np.sort(mono, axis=1) == np.sort(mono[[0] * (r + 1) + [r + 1] * (r + 1) + [2 * (r + 1)] * (r + 1)], axis=1)).all()
+    assert (mono != di).any()
+
+
+def _run_poison(pattern, widths, n):
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from scanfold_amd import _lib\n"
+        "eng = _lib.Engine(0)\n"
+        "for W in %r:\n"
+        "    arr = np.frombuffer(b'ACGU', dtype=np.uint8)[np.random.default_rng(W).integers(0, 4, (%d, W))]\n"
+        "    e, db = eng.mfe_trace_batch(arr[:64])\n"
+        "    print(W, int(eng.mfe_batch(arr).astype(np.int64).sum()), int(e.sum()), hash(tuple(db)) & 0xffffffff)\n"
+        % (ROOT, list(widths), n))
+    env = dict(os.environ, PYTHONHASHSEED="0")
+    if pattern is None:
+        env.pop("SCANFOLD_MFE_POISON", None)
+    else:
+        env["SCANFOLD_MFE_POISON"] = str(pattern)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    return p.stdout
+
+
+def test_poisoned_lds_slack_does_not_move_an_energy(gpu_engine, oracle):
+    """The straight-line cell code of the short diagonals reads candidates of loop sizes that do not exist yet — up to 23
+    words past a rolling row, past the last row into what follows the table — and must be indifferent to what it finds there
+    (the size tables charge those sizes 32 767).  SCANFOLD_MFE_POISON=k makes every workgroup refill, before EVERY fold,
+    each LDS byte that is not a live table of that fold (the rolling rows no diagonal has written yet, the mirror rows, the
+    cell lists, the unused end of the fML area) with an adversarial int16 pattern: -32 768, -28 000, 0, 32 767, or a different
+    one of them per entry.  Energies and structures must equal the unpoisoned run at every width class (narrow merged-helper,
+    W = 120, generic narrow, wide, W = 200) — and the oracle."""
+    widths = (16, 31, 64, 77, 100, 117, 120, 128, 129, 160, 200, 256)
+    base = _run_poison(None, widths, 1500)
+    for pattern in (1, 2, 3, 4, 5):
+        assert _run_poison(pattern, widths, 1500) == base, "pattern %d" % pattern
+    # the unpoisoned run is the oracle's (one width per instantiation)
+    for W in (77, 120, 200):
+        arr = random_seqs(np.random.default_rng(W), 1500, W)
+        assert (gpu_engine.mfe_batch(arr) == oracle.mfe_batch(arr)).all()

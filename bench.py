@@ -236,7 +236,7 @@ def live_counters_per_fold(config, shuffle, input_kind, groups, windows=0, timeo
     return out, None
 
 
-def calibrated_unit_fractions(sec, W, folds_per_launch, launch_ms, eng, n_cu=256):
+def calibrated_unit_fractions(sec, W, folds_per_launch, launch_ms, eng=None, n_cu=256):
     """How busy the vector ALUs and the LDS were during the timed launch: instructions per fold (SQ counters) x the folds of
     a launch x the MEASURED cost of an instruction of this kernel's mix at its occupancy (profiles/r04/mfe_issue_rates.json:
     tools/micro/issue_rates.hip, valu_classes.hip; vector mix from the ISA of the hot blocks) / the launch's duration by HIP
@@ -246,7 +246,7 @@ def calibrated_unit_fractions(sec, W, folds_per_launch, launch_ms, eng, n_cu=256
     path = os.path.join(ROOT, "profiles", "r04", "mfe_issue_rates.json")
     try:
         rates = json.load(open(path))
-        name = eng.device_name()
+        name = eng.device_name() if eng is not None else ""
         if "CUs" in name:
             n_cu = int(name.split(",")[-1].split()[0])
     except Exception as e:
@@ -446,6 +446,9 @@ def main():
                     break
                 except Exception:
                     pass
+        if secondary and "valu_issue_frac" not in secondary and "lds_idx_active_per_fold" in secondary:
+            secondary = dict(secondary)
+            secondary.update(calibrated_unit_fractions(secondary, W, folds_per_launch, avg_ms, eng))
         traffic_src = counters_src and (counters_src + " (rocprofv3 --pmc passes of an earlier run, committed)")
         secondary_src = counters_src and (counters_src + " (SQ counter passes of an earlier run, committed)")
         if world == 1 and not args.no_live_counters:

@@ -88,11 +88,7 @@
 #ifndef SF_FAST_WAVES_PER_SIMD
 #define SF_FAST_WAVES_PER_SIMD 4  // 4 workgroups of 4 waves per CU (W <= 128): at most 128 VGPRs
 #endif
-// timing experiment only (wrong energies): the bulge / 1xn ring aliased onto the fML triangle, so that the footprint allows
-// five or six workgroups per CU — what would a smaller layout buy?  (profiles/r04/mfe_occupancy_bound.txt)
-#ifndef SF_EXP_ALIAS
-#define SF_EXP_ALIAS 0
-#endif
+// (what five or six workgroups per CU would buy if a layout allowed them: profiles/r04/mfe_occupancy_bound.txt)
 
 struct SfFastParams {
   int32_t NIN[32];   // [a]  min(max_ninio, a * ninio)
@@ -251,8 +247,8 @@ static inline __host__ __device__ SfFastLayout sf_fast_layout(int W, bool hc = f
   // (ring row 0 only ever holds the diagonals NR, 2 NR, ...: at most W - NR cells, so that is all the mirror rows keep)
   const int mirror = (W <= 128 && W > SF_FAST_NR) ? ((W - SF_FAST_NR + 1) & ~1) : 0;  // entries
   L.off_ci = o; o += roll + mirror * 2;  // the exterior pass reuses this area for f5[] and the mismatchExt table
-  L.off_c1n = SF_EXP_ALIAS ? 0 : o; o += SF_EXP_ALIAS ? 0 : roll;
-  L.off_cb = o; o += SF_EXP_ALIAS ? 0 : roll;
+  L.off_c1n = o; o += roll;
+  L.off_cb = o; o += roll;
   L.off_dml = o;  // (end of the rolling tables; the rolling rows of multiloop-split minima that used to follow are gone)
   // the interleaved bulge / 1xn table gets row NR = a copy of its row 0 as well ("the row after row r" exists for every r: the
   // merged helper relies on it too); W < SF_HELP_MERGE_MAXW (merged helper): each of the two helper waves a 128-byte list of cells
@@ -1453,9 +1449,6 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
     // finds is energy-sized.  Until round 4 the tables were initialised once per workgroup and later folds found the
     // previous fold's energies there — as good, unless that fold had left the int16 range.  24 dword stores per thread
     // and fold (0.05 % of a fold) make a fold's result a function of its own sequence only.
-#ifdef SF_EXP_NOREINIT
-    if (seq == (int)blockIdx.x)
-#endif
     for (int x = tid; x < (Lo.off_tab - Lo.off_ci) / 4; x += NT) ((uint32_t *)X.CI)[x] = sf_pk(SF_INF16, SF_INF16);
     int fetched = 0;
     if (tid == 0) {

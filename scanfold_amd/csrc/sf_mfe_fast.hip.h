@@ -379,6 +379,24 @@ __device__ __forceinline__ void sf_fast_publish_bn(int16_t *w, const int i0, con
   }
 }
 
+// Entry idx of an int16 table inside the parameter block (wave-uniform base F): the byte offset — the table's place in the block
+// included — is formed in 32 bits, so that the load is "scalar base + 32-bit vector offset" (global_load saddr).  From
+// F->tab[idx] the compiler builds a 64-bit address per lane (v_mad_u64_u32, v_lshl_add_u64, add / addc with carry: ~5
+// half-rate vector instructions per gather, four gathers per cell pass).
+#ifdef SF_EMUL
+#define SF_GATHER16(F, field, idx) ((int)(F)->field[idx])
+#else
+// (the offset passes through an empty asm: otherwise the compiler splits the table's constant back off into a 64-bit add)
+__device__ __forceinline__ int sf_gather16_at(const void *base, unsigned off) {
+  asm("" : "+v"(off));
+  return *(const int16_t *)((const char *)base + (size_t)off);
+}
+// (the wide kernel only: +2.7 % at W = 200, +1 % at W = 160; the narrow kernel measured 2-3 % SLOWER with it — fewer vector
+// instructions but the gathers' addresses are ready later and its waits grow — and keeps the plain form)
+#define SF_GATHER16(F, field, idx) \
+  (FOLD ? sf_gather16_at((F), (unsigned)offsetof(SfFastParams, field) + ((unsigned)(idx) << 1)) : (int)(F)->field[idx])
+#endif
+
 // One anti-diagonal for one thread.  H: this parity's per-size minima of the generic candidates of the
 // enclosed cell (i+1, j-1) on entry, of (i, j) on exit.  slot2 = (d-2) mod NR, slotd = d mod NR.
 // G ("guarded"): d < 36, the loop-size limit d-6 is below MAXLOOP and every size is tested against it;
@@ -575,19 +593,19 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
       }
       if (!G || (UCAP >= 2 && umax >= 2)) {  // 1 x 1: (i+2, j-2)
         const unsigned t2r = RP[S[i + 2] * 8 + S[j - 2]];
-        eh = sfd_min(eh, BNROWB(ROWB_BN(2))[2 * 2] + Fc->int11T[((tq + t2r) * 5u + si1) * 5u + sj1]);
+        eh = sfd_min(eh, BNROWB(ROWB_BN(2))[2 * 2] + SF_GATHER16(Fc, int11T, ((tq + t2r) * 5u + si1) * 5u + sj1));
       }
       if (!G || (UCAP >= 3 && umax >= 3)) {  // 1 x 2 and 2 x 1
         const int16_t *row = BNROWB(ROWB_BN(3));
         const unsigned ta = RP[S[i + 2] * 8 + S[j - 3]];  // (i+2, j-3), sq1 = S[j-2]
-        eh = sfd_min(eh, row[2 * 2] + Fc->int21a[(((tq + ta) * 5u + si1) * 5u + S[j - 2]) * 5u + sj1]);
+        eh = sfd_min(eh, row[2 * 2] + SF_GATHER16(Fc, int21a, (((tq + ta) * 5u + si1) * 5u + S[j - 2]) * 5u + sj1));
         const unsigned tb = RP[S[i + 3] * 8 + S[j - 2]];  // (i+3, j-2), sp1 = S[i+2]
-        eh = sfd_min(eh, row[2 * 3] + Fc->int21b[(((tb * 8u + type) * 5u + sj1) * 5u + si1) * 5u + S[i + 2]]);
+        eh = sfd_min(eh, row[2 * 3] + SF_GATHER16(Fc, int21b, (((tb * 8u + type) * 5u + sj1) * 5u + si1) * 5u + S[i + 2]));
       }
       if (!G || (UCAP >= 4 && umax >= 4)) {  // 2 x 2: (i+3, j-3)
         const unsigned t2r = RP[S[i + 3] * 8 + S[j - 3]];
         eh = sfd_min(eh, BNROWB(ROWB_BN(4))[2 * 3] +
-                             Fc->int22T[((((tq + t2r) * 5u + si1) * 5u + S[i + 2]) * 5u + S[j - 2]) * 5u + sj1]);
+                             SF_GATHER16(Fc, int22T, ((((tq + t2r) * 5u + si1) * 5u + S[i + 2]) * 5u + S[j - 2]) * 5u + sj1));
       }
       if (!G || (UCAP >= 5 && umax >= 5)) {  // 2 x 3 and 3 x 2
         const int16_t *row = BNROWB(ROWB_BN(5));

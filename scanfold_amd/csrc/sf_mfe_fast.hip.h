@@ -939,7 +939,7 @@ __device__ __forceinline__ int sf_fast_dml2(const SfFastCtx &X, const int d, con
   const int q = lane & ((1 << lg) - 1), c = lane >> lg;
   const int elast = (d & 1) ? d - 6 : d - 5;            // last term of the batched range (odd)
   const int N = elast - 3;                              // terms 4 .. elast (an even number)
-  const int S = (((N + NC - 1) / NC) + 1) & ~1;         // a chunk's share, even
+  const int S = (((N + NC - 1) >> (6 - lg)) + 1) & ~1;  // a chunk's share, even (NC = 64 >> lg: a shift, not a division by a run-time value)
   const int T8 = (S + 7) & ~7;                          // what it runs: whole batches
   const int ms = sfd_min(4 + c * S, elast - T8 + 1);    // per lane (per chunk), even
   const int ys = d - 1 - ms;

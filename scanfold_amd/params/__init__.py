@@ -113,8 +113,10 @@ class ParamSet:
             return base
         if self.dH is None:
             raise NotImplementedError(
-                "folding temperature %s C: parameter set %s has no enthalpy tables (it is valid at 37 C only); load a "
-                "ViennaRNA .par file that has *_enthalpies sections" % (temperature_c, self.source))
+                "folding temperature %s C: parameter set %s has no enthalpy tables (it is valid at 37 C only).  Pass ViennaRNA's "
+                "own parameter file — `--params <ViennaRNA prefix>/share/ViennaRNA/rna_turner2004.par` on the command line, "
+                "params.load_par(path) in code — whose *_enthalpies sections the rescale needs; the shipped default is a "
+                "37 C reconstruction without them" % (temperature_c, self.source))
         tempf = (t + K0) / T_MEASURE
         out = self.rec37.copy()
         for f in _RESCALED:

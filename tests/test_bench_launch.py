@@ -35,3 +35,25 @@ def test_gpus_2_spawns_two_ranks_and_fails_only_at_device_selection():
 def test_world_size_mismatch_is_reported():
     out = run_bench("--gpus", "1", env={"RANK": "0", "WORLD_SIZE": "2", "LOCAL_RANK": "0"})
     assert out.returncode == 2 and "WORLD_SIZE=2" in out.stderr
+
+
+def test_calibrated_unit_fractions_from_the_committed_rates():
+    """bench.py's roofline.secondary: instruction counts x the instruction costs measured on MI355X (profiles/r04/
+    mfe_issue_rates.json: tools/micro/issue_rates.hip, valu_classes.hip) / the launch time.  The committed cfg3 counters must
+    reproduce the fractions the committed bench line carries, and the rates file must say what it was measured on."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    rates = json.load(open(os.path.join(ROOT, "profiles", "r04", "mfe_issue_rates.json")))
+    assert 0.9 < rates["valu_full_rate_ns"] < 1.3 and 1.6 < rates["valu_half_rate_ns"] < 2.2
+    assert "v_pk_min_i16" in rates["valu_half_rate_opcodes"] and "v_add_u32" in rates["valu_full_rate_opcodes"]
+    line = json.load(open(os.path.join(ROOT, "profiles", "r04", "final_bench.json")))
+    sec = line["roofline"]["secondary"]
+    got = bench.calibrated_unit_fractions(sec, 120, line["roofline"]["folds_per_launch"], line["roofline"]["avg_launch_ms"])
+    assert abs(got["valu_issue_frac"] - sec["valu_issue_frac"]) < 1e-9 and abs(got["lds_frac"] - sec["lds_frac"]) < 1e-9
+    assert 0.5 < got["valu_issue_frac"] < 1.0 and got["binding_unit"] == "valu"
+    # the counters file bench.py falls back to (--no-live-counters) describes the same launch
+    cnt = json.load(open(os.path.join(ROOT, "profiles", "r04", "mfe_counters.json")))
+    assert cnt["folds"] == 3017981 and cnt["launches"] == 1
+    assert abs(cnt["secondary"]["valu_insts_per_fold"] / sec["valu_insts_per_fold"] - 1) < 0.02
+    assert abs(cnt["hbm_bytes_per_launch"] / line["roofline"]["traffic"] - 1) < 0.05

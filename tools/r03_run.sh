@@ -40,7 +40,7 @@ for k in (1, 2, 3):
     sq.update(pmc_sum(O + "/sq_%d/*/*counter_collection.csv" % k, "sf_mfe_fast_kernel", 1024 * 128))
 N = 131072.0
 per_fold = {k: v / N for k, v in sq.items()}
-out = {"source": "tools/r02_run.sh on MI355X; rocprofv3 --pmc passes, one counter group per run",
+out = {"source": "tools/r03_run.sh on MI355X; rocprofv3 --pmc passes, one counter group per run (superseded by tools/r04_run.sh: counters of the timed workload, no warm-up launch)",
        "hbm_bytes_per_launch": (2 * fetch.get("FETCH_SIZE", 0) + write.get("WRITE_SIZE", 0)) * 1024,
        "hbm_note": "MFE kernel launch of one cfg3 step (3 017 981 folds, the largest dispatch of the pass): 2 x FETCH_SIZE (gfx950 reports half of a read) + WRITE_SIZE, KB -> bytes; L2 <-> fabric traffic, Infinity-Cache hits included (profiles/r03/mfe_scratch_traffic.txt)",
        "fetch_size_kb": fetch.get("FETCH_SIZE"), "write_size_kb": write.get("WRITE_SIZE"),

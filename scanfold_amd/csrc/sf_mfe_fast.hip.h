@@ -397,6 +397,20 @@ __device__ __forceinline__ int sf_gather16_at(const void *base, unsigned off) {
   (FOLD ? sf_gather16_at((F), (unsigned)offsetof(SfFastParams, field) + ((unsigned)(idx) << 1)) : (int)(F)->field[idx])
 #endif
 
+#ifdef SF_EMUL
+// TEST BUILD ONLY: every row of the interleaved bulge / 1xn view a cell reads must be one of the ring's NR rows or the mirror row
+// behind them (the kernel records the view's base per workgroup; fibers of one emulated workgroup run in one thread)
+static thread_local const char *sf_emul_bn_base = nullptr;
+static inline void sf_emul_check_bn_row(const char *row_ptr, long lane_bytes, long row_bytes, bool fold) {
+  if (!sf_emul_bn_base) return;
+  const long row = (row_ptr - sf_emul_bn_base - lane_bytes) / row_bytes;
+  if (row < 0 || row > (fold ? SF_FAST_NR - 1 : SF_FAST_NR)) {
+    fprintf(stderr, "sf_mfe_fast (emulation): bulge / 1xn row %ld outside the ring and its mirror row\n", row);
+    abort();
+  }
+}
+#endif
+
 // One anti-diagonal for one thread.  H: this parity's per-size minima of the generic candidates of the
 // enclosed cell (i+1, j-1) on entry, of (i, j) on exit.  slot2 = (d-2) mod NR, slotd = d mod NR.
 // G ("guarded"): d < 36, the loop-size limit d-6 is below MAXLOOP and every size is tested against it;
@@ -426,7 +440,12 @@ struct SfPub {
 // TBLK: the rolling rows' offsets come from the SfFastRows table (scalar loads) instead of the ring arithmetic — the kernel
 // decides per instantiation (measured: +4 % at W = 120 / 200, +3 % at W = 128; the merged-helper and the generic wide
 // instantiations, which already spill, lose 1-2 % and keep the arithmetic)
-template <bool G, int WT, int SEC, bool CH = false, bool FOLD = false, int UCAP = SFD_MAXLOOP, bool TBLK = true>
+// MGH: the call is the merged helper's (a lane's cell may lie on the step's odd diagonal: its rows are the even diagonal's plus one,
+// X.BN shifted by a row) — it must not reach a row through "the row after the next size's row": that is row + 2 for such a lane,
+// and only ONE mirror row follows the ring.  (Until round 4 it did: for slot2 == u, u even, the odd diagonal's lanes read "row 35",
+// i.e. the cell lists / parameter tables behind the mirror row.  The results stayed exact in every test because that garbage either
+// lost the minimum or tripped the int16-overflow fallback — found when the lists were moved in an experiment, profiles/r04.)
+template <bool G, int WT, int SEC, bool CH = false, bool FOLD = false, int UCAP = SFD_MAXLOOP, bool TBLK = true, bool MGH = false>
 __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, const int i, const bool valid,
                                              const int slot2, const int slotd, uint32_t (&HP)[14], int &ovf,
                                              const bool final_fml, const int fnb, int &fpart, int &dec, int &eh, int &e0,
@@ -648,7 +667,10 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
             const int u = ub + k;
             if (u <= 30) {
               // (!FOLD: sizes (u, u+1), u even, share a base — row u is the row after row u+1, the mirror row at the ring's seam)
-              const int16_t *tp = (FOLD || u == 30) ? BNROWB(ROWB_BN(u)) : BNROWB(ROWB_BN(u | 1)) + ((u & 1) ? 0 : 2 * RW);
+              const int16_t *tp = (FOLD || MGH || u == 30) ? BNROWB(ROWB_BN(u)) : BNROWB(ROWB_BN(u | 1)) + ((u & 1) ? 0 : 2 * RW);
+#ifdef SF_EMUL
+              sf_emul_check_bn_row((const char *)tp, 4 * i0, 4 * RW, FOLD);
+#endif
               w0[k] = sf_ldw(tp + 2 * 1);
               if (!SHIFT) w1[k] = sf_ldw(tp + 2 * 2);
               w2[k] = sf_ldw(tp + 2 * (SHIFT ? u - 1 : u)); w3[k] = sf_ldw(tp + 2 * (u + 1));
@@ -1359,6 +1381,9 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
   X.CI = (int16_t *)(smem + Lo.off_ci);
   X.C1N = nullptr; X.CB = nullptr;
   X.BN = (int16_t *)(smem + Lo.off_c1n);  // spans the two areas
+#ifdef SF_EMUL
+  sf_emul_bn_base = (const char *)X.BN;
+#endif
   X.DMLr = nullptr;  // (the multiloop split of the enclosed cell is carried in a register: same thread, two diagonals earlier)
   int16_t *tab = (int16_t *)(smem + Lo.off_tab);
   // Pair types are 1..6, so only those rows of a [type][5][5] table exist here and the pointers are biased by
@@ -1589,7 +1614,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
             const int sd1 = sd0 + 1 >= SF_FAST_NR ? 0 : sd0 + 1;
             SfFastCtx Xh = X;
             Xh.BN = X.BN + 2 * g * (W - 4);
-            sf_fast_cell<false, WT, SF_SEC_HELP, false, FOLD, SFD_MAXLOOP, TBLK>(Xh, d0 + g, iC, vC, s2, sd0, H, ovf, false, fnb, fpart, dec, eh, e0, dprev, pub);
+            sf_fast_cell<false, WT, SF_SEC_HELP, false, FOLD, SFD_MAXLOOP, TBLK, true>(Xh, d0 + g, iC, vC, s2, sd0, H, ovf, false, fnb, fpart, dec, eh, e0, dprev, pub);
             if (vC) X.BN[2 * ((g ? sd1 : sd0) * (W - 4) + iC - 1)] = (int16_t)sfd_min(eh, 32000);
           }
         } else {

@@ -60,11 +60,16 @@
 #define SF_FAST_DML2 1   // ... and the first runs the multiloop split two cells per lane, the lanes in chunks over the terms
 // split steps at W <= 128: 1 = ONE helper wave serves both diagonals of a step, on a compacted list of the cells that
 // can pair (3 of 8): the special / bulge / 1xn block runs once per step instead of twice
-// (W < SF_HELP_MERGE_MAXW only.  With folds handed out dynamically the merge measures +3.6 % at W=80, +2.3 % at W=100,
+// (W < SF_HELP_MERGE_MAXW, and the W = 120 instantiation: SF_MG120.  With folds handed out dynamically the merge measures +3.6 % at W=80, +2.3 % at W=100,
 // +1.1 % at W=110, +1.5 % at W=116 and -2.9 % at W=120, -1.4 % at W=128: the compacted lanes read scattered words, three or four deep
 // in the LDS banks, and at the widths where LDS cycles are tightest that costs more than the saved pass.)
 #define SF_HELP_MERGE_MAXW 118
 #define SF_HELP_MERGE 1
+// the W = 120 instantiation runs the merged helper too (round 4: +1.1 %, 59.5 -> 58.8 ms per 262 144 folds) — its cell lists take the
+// place of the LDS copy of the size tables (see cell_list in the kernel); the generic instantiation keeps the W < 118 rule
+#ifndef SF_MG120
+#define SF_MG120 1
+#endif
 // split steps at W > 128 (four waves per diagonal): 1 = the group's outer waves help the two middle ones
 #define SF_FAST_SPLIT_256 1
 // split steps of the wide kernel (NG = 256, where the split is most of a cell): the helper waves take (terms / 2 - bias)
@@ -400,12 +405,20 @@ __device__ __forceinline__ int sf_gather16_at(const void *base, unsigned off) {
 #ifdef SF_EMUL
 // TEST BUILD ONLY: every row of the interleaved bulge / 1xn view a cell reads must be one of the ring's NR rows or the mirror row
 // behind them (the kernel records the view's base per workgroup; fibers of one emulated workgroup run in one thread)
-static thread_local const char *sf_emul_bn_base = nullptr;
+static thread_local const char *sf_emul_bn_base = nullptr, *sf_emul_ci_base = nullptr;
 static inline void sf_emul_check_bn_row(const char *row_ptr, long lane_bytes, long row_bytes, bool fold) {
   if (!sf_emul_bn_base) return;
   const long row = (row_ptr - sf_emul_bn_base - lane_bytes) / row_bytes;
   if (row < 0 || row > (fold ? SF_FAST_NR - 1 : SF_FAST_NR)) {
     fprintf(stderr, "sf_mfe_fast (emulation): bulge / 1xn row %ld outside the ring and its mirror row\n", row);
+    abort();
+  }
+}
+static inline void sf_emul_check_ci_row(const int16_t *row_ptr, long lane_entries, long row_entries, bool fold) {
+  if (!sf_emul_ci_base) return;
+  const long row = ((const char *)row_ptr - sf_emul_ci_base - 2 * lane_entries) / (2 * row_entries);
+  if (row < 0 || row > (fold ? SF_FAST_NR - 1 : SF_FAST_NR)) {
+    fprintf(stderr, "sf_mfe_fast (emulation): generic-loop row %ld outside the ring and its mirror row\n", row);
     abort();
   }
 }
@@ -555,6 +568,9 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
         const int u = 2 * (pb - k) + 4;
         // (!FOLD: row u is the row after row u+1 — the mirror row when that is the ring's last — at a compile-time offset)
         const int16_t *rb = CIROW(u + 1) + i0, *ra = FOLD ? CIROW(u) + i0 : rb + RW;
+#ifdef SF_EMUL
+        sf_emul_check_ci_row(ra, i0, RW, FOLD); sf_emul_check_ci_row(rb, i0, RW, FOLD);
+#endif
         e1[k] = sf_pk(ra[3], rb[3]);          // u1 = 2
         e2[k] = sf_pk(ra[u - 1], rb[u]);      // u2 = 2
         nn[k] = sf_ldw(uNIN + (u - 4));
@@ -1382,7 +1398,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
   X.C1N = nullptr; X.CB = nullptr;
   X.BN = (int16_t *)(smem + Lo.off_c1n);  // spans the two areas
 #ifdef SF_EMUL
-  sf_emul_bn_base = (const char *)X.BN;
+  sf_emul_bn_base = (const char *)X.BN; sf_emul_ci_base = (const char *)X.CI;
 #endif
   X.DMLr = nullptr;  // (the multiloop split of the enclosed cell is carried in a register: same thread, two diagonals earlier)
   int16_t *tab = (int16_t *)(smem + Lo.off_tab);
@@ -1405,7 +1421,11 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
   constexpr bool MERGE = MG && SF_HELP_MERGE && (NG == 128);
   constexpr bool TBLK = WT > 0 || (NG == 128 && !MG);  // rolling-row offsets from SfFastRows (see sf_fast_cell)
   X.bn_dup = (NG == 128);
-  uint8_t *const cell_list = (uint8_t *)(smem + Lo.off_list);
+  // (W >= SF_HELP_MERGE_MAXW with the merged helper — the W = 120 instantiation: its two 128-byte cell lists do not fit the 40 960 B
+  // of four workgroups per CU, so they take the place of the LDS copy of the size tables, which only the first four steps of a fold
+  // read — long before the first list is built — and which is copied again for every fold)
+  uint8_t *const cell_list = (MG && W >= SF_HELP_MERGE_MAXW) ? (uint8_t *)((int16_t *)(smem + Lo.off_tab) + 1069 + 32 + 1)
+                                                            : (uint8_t *)(smem + Lo.off_list);
   X.TAU = D->P.TerminalAU; X.MLbase = D->P.MLbase; X.MLclosing = D->P.MLclosing; X.MLintern = D->P.MLintern[1];
   // exterior pass aliases (the rolling CI area is dead by then)
   int32_t *f5s = (int32_t *)(smem + Lo.off_ci);
@@ -1486,6 +1506,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
       __syncthreads();
     }
     for (int x = tid; x < W; x += NT) S[x + 1] = sf_encode_nt(src[x]);
+    if (MG && W >= SF_HELP_MERGE_MAXW) for (int x = tid; x < 128; x += NT) ((int16_t *)(smem + Lo.off_tab) + 1069 + 32 + 1)[x] = F->uni[x];
     // The rolling tables (with their mirror rows and the cell lists) start every fold as "no structure".  The straight-line
     // cell code of the short diagonals reads candidates of loop sizes that do not exist yet — rows no diagonal of this fold
     // has written, up to 23 words past the end of a row — and charges them 32 767; the sum only stays "none" if what it
@@ -1714,7 +1735,7 @@ static inline hipError_t sf_fast_configure() {
   hipError_t e;
   if ((e = sf_fast_configure_one<128, 0>()) != hipSuccess) return e;
   if ((e = sf_fast_configure_one<128, 0, true>()) != hipSuccess) return e;
-  if ((e = sf_fast_configure_one<128, 120>()) != hipSuccess) return e;
+  if ((e = sf_fast_configure_one<128, 120, SF_MG120 != 0>()) != hipSuccess) return e;
   if ((e = sf_fast_configure_one<256, 200>()) != hipSuccess) return e;
   if ((e = sf_fast_configure_one<256, 0>()) != hipSuccess) return e;
   // the instantiations for constrained folds (generic widths only)
@@ -1724,7 +1745,7 @@ static inline hipError_t sf_fast_configure() {
   // the poison builds (SCANFOLD_MFE_POISON: tests only)
   if ((e = sf_fast_configure_one<128, 0, false, false, true>()) != hipSuccess) return e;
   if ((e = sf_fast_configure_one<128, 0, true, false, true>()) != hipSuccess) return e;
-  if ((e = sf_fast_configure_one<128, 120, false, false, true>()) != hipSuccess) return e;
+  if ((e = sf_fast_configure_one<128, 120, SF_MG120 != 0, false, true>()) != hipSuccess) return e;
   if ((e = sf_fast_configure_one<256, 200, false, false, true>()) != hipSuccess) return e;
   return sf_fast_configure_one<256, 0, false, false, true>();
 }
@@ -1755,7 +1776,7 @@ static inline void sf_fast_geometry(int W, int n_cu, int n, int *grid, int *thre
 template <bool PZ, typename... A>
 static inline void sf_fast_launch_pz(int grid, int threads, size_t lds, hipStream_t st, const uint8_t *seqs, int n, int W,
                                      A... args) {
-  if (threads == 256 && W == 120) SF_LAUNCH((sf_mfe_fast_kernel<128, 120, false, false, PZ>), grid, 256, lds, st, seqs, n, W, args...);
+  if (threads == 256 && W == 120) SF_LAUNCH((sf_mfe_fast_kernel<128, 120, SF_MG120 != 0, false, PZ>), grid, 256, lds, st, seqs, n, W, args...);
   else if (threads == 256 && W < SF_HELP_MERGE_MAXW && SF_HELP_MERGE) SF_LAUNCH((sf_mfe_fast_kernel<128, 0, true, false, PZ>), grid, 256, lds, st, seqs, n, W, args...);
   else if (threads == 256) SF_LAUNCH((sf_mfe_fast_kernel<128, 0, false, false, PZ>), grid, 256, lds, st, seqs, n, W, args...);
   else if (W == 200) SF_LAUNCH((sf_mfe_fast_kernel<256, 200, false, false, PZ>), grid, 512, lds, st, seqs, n, W, args...);

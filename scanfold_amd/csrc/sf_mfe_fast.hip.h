@@ -72,6 +72,9 @@
 #endif
 // split steps at W > 128 (four waves per diagonal): 1 = the group's outer waves help the two middle ones
 #define SF_FAST_SPLIT_256 1
+#ifndef SF_FAST_NARROW_256
+#define SF_FAST_NARROW_256 1  // ... and from the diagonal where a diagonal's cells fit one wave on, one main + one helper wave (NARROW in the kernel)
+#endif
 // split steps of the wide kernel (NG = 256, where the split is most of a cell): the helper waves take (terms / 2 - bias)
 // terms of the multiloop split, the ones with the largest m.  The narrow kernel's helpers take none: their special-loop
 // work already balances the main wave (any share measured the same or worse in rounds 2 and 3).
@@ -1467,6 +1470,15 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
   constexpr int MAIN_LO = (NG == 256) ? 64 : 0, MAIN_HI = (NG == 256) ? 191 : 63;
   const bool can_split = SF_FAST_SPLIT && ((NG == 128 && W >= 64) || (NG == 256 && SF_FAST_SPLIT_256));
   const int split_d0 = can_split ? ((sfd_max(sfd_max(SFD_MAXLOOP + 6, 2 * (MAIN_LO - 1 + OFFs)), 2 * (W - OFFs - MAIN_HI)) + 1) & ~1) : 1 << 30;
+  // NARROW (wide kernel, round 4): from the even diagonal where the cells of a diagonal fit ONE wave (lanes 96..159 of the group,
+  // <= 62 cells: d0 >= 138 at W = 200) the two main + two helper waves of a group are twice what the work needs — both mains
+  // run the whole cell code on <= 31 cells each.  The cells move 32 lanes down into the group's wave 1 (main), wave 0 mirrors it
+  // (helper), waves 2 and 3 only keep the barriers; the per-thread state that follows a centre (the recurrence's 14 registers,
+  // the enclosed cell's split minimum, the even group's neighbour term) changes lanes ONCE, through the unused ends of 32 rows of
+  // the interleaved ring (a row holds <= 94 cells by then: dwords 100..163 of each row are free; needs W - 4 >= 164).
+  constexpr bool NARROW = (NG == 256) && SF_FAST_NARROW_256;
+  const int narrow_d0 = (NARROW && can_split && W >= 168)
+                            ? sfd_max(split_d0, (sfd_max(2 * (96 - 1 + OFFs), 2 * (W - OFFs - 159)) + 1) & ~1) : 1 << 30;
 
   // trailing exterior sweep (see SfTrail): wave 3 (the helper of the odd group) sweeps the rows of this fold's scratch
   // that are already complete
@@ -1583,9 +1595,31 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
       // then the first wave finishes the cell.  The dependent chain of such a step is ~45 % shorter.
       const bool split = d0 >= split_d0;
       // helper lanes mirror a main lane 64 away: NG = 128: wave 1 -> wave 0; NG = 256: wave 0 -> wave 1, wave 3 -> wave 2
-      const bool helper = split && (NG == 256 ? (tg < 64 || tg >= 192) : tg >= 64);
-      const int vh = NG == 256 ? (tg < 64 ? v + 64 : v - 64) : v - 64;
-      const int i = (helper ? (vh & (NG - 1)) : v) - (d >> 1);
+      const bool narrow = NARROW && d0 >= narrow_d0;
+      if (NARROW && d0 == narrow_d0) {
+        // the one-time move of the centres' state: old owners tg = 96..159 -> new owners tg - 32 = 64..127
+        uint32_t *const xa = (uint32_t *)X.BN;  // dword = cell of the interleaved ring; row r, cell 100 + lane
+        const int RWc = W - 4;
+        if (tg >= 96 && tg < 160) {
+#pragma unroll
+          for (int k = 0; k < 14; k++) xa[(grp * 16 + k) * RWc + 100 + (tg - 96)] = H[k];
+          xa[(grp * 16 + 14) * RWc + 100 + (tg - 96)] = (uint32_t)dprev;
+          xa[(grp * 16 + 15) * RWc + 100 + (tg - 96)] = (uint32_t)fnb;
+        }
+        __syncthreads();
+        if (tg >= 64 && tg < 128) {
+#pragma unroll
+          for (int k = 0; k < 14; k++) H[k] = xa[(grp * 16 + k) * RWc + 100 + (tg - 64)];
+          dprev = (int)xa[(grp * 16 + 14) * RWc + 100 + (tg - 64)];
+          fnb = (int)xa[(grp * 16 + 15) * RWc + 100 + (tg - 64)];
+        }
+        __syncthreads();
+      }
+      const bool helper = split && (NG == 256 ? (narrow ? tg < 64 : (tg < 64 || tg >= 192)) : tg >= 64);
+      const int vh = NG == 256 ? (narrow ? v + 96 : (tg < 64 ? v + 64 : v - 64)) : v - 64;
+      // (narrow: lanes 64..127 take the cells of lanes 96..159, lanes 0..63 mirror them; lanes >= 128 have no cell)
+      const int vm = (NARROW && narrow) ? ((v + 32) & (NG - 1)) : v;
+      const int i = (NARROW && narrow && tg >= 128) ? -1 : ((helper ? (vh & (NG - 1)) : vm) - (d >> 1));
       // split step: the multiloop split (d-8 terms, the part of a cell that grows with d) is shared with the helper
       // wave: terms m >= dml_cut are the helper's (wave-uniform; both waves of a cell compute the same cut)
       const int dml_terms = d - 2 * SFD_TURN - 2;  // m = 4 .. d-5

@@ -1619,7 +1619,16 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
       const int vh = NG == 256 ? (narrow ? v + 96 : (tg < 64 ? v + 64 : v - 64)) : v - 64;
       // (narrow: lanes 64..127 take the cells of lanes 96..159, lanes 0..63 mirror them; lanes >= 128 have no cell)
       const int vm = (NARROW && narrow) ? ((v + 32) & (NG - 1)) : v;
-      const int i = (NARROW && narrow && tg >= 128) ? -1 : ((helper ? (vh & (NG - 1)) : vm) - (d >> 1));
+      // (narrow: waves 2 and 3 of the group would idle — they mirror the main wave too and take most of the multiloop split, the
+      // part of a cell that keeps growing with d: 40 % of the terms each, the main wave the first fifth; their partial minima
+      // cross in the dwords the centres' state moved through)
+      // (the W = 200 instantiation only: +4 % there; the generic wide instantiation measured 2-6 % SLOWER with it at W = 168 / 256 and
+      // leaves those waves without cells)
+      constexpr bool DML4 = NARROW && (WT == 200);
+      const bool dmlw = DML4 && narrow && tg >= 128;
+      const int vd = tg >= 192 ? v - 96 : v - 32;
+      const int i = (NARROW && !DML4 && narrow && tg >= 128) ? -1
+                    : ((dmlw ? (vd & (NG - 1)) : (helper ? (vh & (NG - 1)) : vm)) - (d >> 1));
       // split step: the multiloop split (d-8 terms, the part of a cell that grows with d) is shared with the helper
       // wave: terms m >= dml_cut are the helper's (wave-uniform; both waves of a cell compute the same cut)
       const int dml_terms = d - 2 * SFD_TURN - 2;  // m = 4 .. d-5
@@ -1644,6 +1653,21 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
         else if (d0 < SF_FAST_TINY_D0) sf_fast_cell<true, WT, SF_SEC_ALL, false, FOLD, 5>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
         else if (d0 < SF_FAST_CHUNK_D0) sf_fast_cell<false, WT, SF_SEC_ALL, true, FOLD, SFD_MAXLOOP, TBLK>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
         else if (!split) sf_fast_cell<false, WT, SF_SEC_ALL, false, FOLD, SFD_MAXLOOP, TBLK>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
+        else if (DML4 && narrow) {
+          // terms m = 4 .. d-5: main [4, cA), wave 2 [cA, cB), wave 3 [cB, d-5]
+          const int nmain = dml_terms / 5, cA = SFD_TURN + 1 + nmain, cB = cA + (dml_terms - nmain + 1) / 2;
+          uint32_t *const xa = (uint32_t *)X.BN;
+          if (dmlw) {
+            const bool wB = tg >= 192;
+            sf_fast_cell<false, WT, SF_SEC_DML, false, FOLD, SFD_MAXLOOP, TBLK>(X, d, i, valid, slot2, slotd, H, ovf, false, fnb, fpart, dec, eh, e0, dprev, pub, wB ? cB : cA, wB ? (1 << 20) : cB - 1);
+            if (valid) xa[(grp * 16 + (wB ? 1 : 0)) * (W - 4) + 100 + (tg & 63)] = (uint32_t)sfd_min(dec, 32000);
+          } else if (!helper) {
+            sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_DML | SF_SEC_PRE, false, FOLD, SFD_MAXLOOP, TBLK>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub, SFD_TURN + 1, cA - 1);
+          } else {
+            sf_fast_cell<false, WT, SF_SEC_HELP, false, FOLD, SFD_MAXLOOP, TBLK>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
+            if (valid) X.BN[2 * (slotd * (W - 4) + i - 1)] = (int16_t)sfd_min(eh, 32000);
+          }
+        }
         else if (!helper) {
           if (SHARE) sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_DML | SF_SEC_PRE, false, FOLD, SFD_MAXLOOP, TBLK>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub, SFD_TURN + 1, dml_cut - 1);
           else if (DML2) {
@@ -1693,10 +1717,13 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
       if (MERGE && grp == 1 && tg >= 64 && d0 + 2 >= split_d0 && d0 + 2 < W) build_list(d0 + 2);
       if (split) {
         __syncthreads();
-        if (!helper && __ballot(valid)) {
+        if (!helper && !dmlw && __ballot(valid)) {
           if (valid) {
             eh = X.BN[2 * (slotd * (W - 4) + i - 1)];
-            if (SHARE) dec = sfd_min(dec, (int)X.CI[slotd * (W - 4) + i - 1]);
+            if (DML4 && narrow) {
+              const uint32_t *const xa = (const uint32_t *)X.BN;
+              dec = sfd_min(dec, sfd_min((int)xa[(grp * 16) * (W - 4) + 100 + (tg & 63)], (int)xa[(grp * 16 + 1) * (W - 4) + 100 + (tg & 63)]));
+            } else if (SHARE) dec = sfd_min(dec, (int)X.CI[slotd * (W - 4) + i - 1]);
           }
           sf_fast_cell<false, WT, SF_SEC_FIN | SF_SEC_POST, false, FOLD, SFD_MAXLOOP, TBLK>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
         }
@@ -1707,7 +1734,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
       // group's next cell (i-1, j+1), which needs the cells i-1 and i of it — so every even lane finishes BOTH
       // (storing only its own, i) and keeps their minimum in a register.  No second barrier: nothing else reads
       // these entries before several later barriers (the multiloop split of d reads spans <= d-5).
-      if (grp == 0 && valid && !helper) {
+      if (grp == 0 && valid && !helper && !dmlw) {
         const int d1 = d0 + 1;
         const int fbd = FBASE(d1), fbe = FBASE(d0);
         int g[2];

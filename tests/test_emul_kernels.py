@@ -64,7 +64,9 @@ def test_fast_kernel_four_wave_groups_with_helper_waves(emul, oracle):
     compositions (long helices: the multiloop split decides), MFE and traceback against the oracle."""
     emul.load_params(params.default_params())
     rng = np.random.default_rng(23)
-    for W in (129, 130, 146, 177, 200, 223, 256):
+    # (167 / 168: the narrow phase — one main + one helper wave per diagonal once a diagonal fits one wave — exists from W = 168 on;
+    # 200: its instantiation also hands the idle waves 80 % of the multiloop split)
+    for W in (129, 130, 146, 167, 168, 177, 200, 223, 256):
         arr = random_seqs(rng, 2, W)
         gc = np.frombuffer(b"GGGCCCAU", dtype=np.uint8)[rng.integers(0, 8, (1, W))]
         arr = np.concatenate([arr, gc])

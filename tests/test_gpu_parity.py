@@ -44,7 +44,7 @@ def test_committed_vectors(gpu_engine):
 
 
 @pytest.mark.parametrize("W,n", [(8, 64), (9, 64), (30, 512), (77, 512), (120, 4096), (128, 256), (129, 256),
-                                  (200, 512), (256, 64), (300, 16), (400, 4), (5, 8)])
+                                  (200, 512), (256, 64), (300, 16), (400, 4), (5, 8), (167, 128), (168, 384), (181, 384)])
 def test_mfe_energy_parity_both_kernels(gpu_engine, oracle, W, n):
     arr = random_seqs(np.random.default_rng(W * 1000 + n), n, W)
     ref = oracle.mfe_batch(arr)

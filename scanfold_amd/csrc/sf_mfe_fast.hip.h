@@ -316,7 +316,19 @@ struct SfFastCtx {
 // channels and lines, and with it how often a partially written line is evicted before its row is complete: at W = 120,
 // L2 -> fabric writes per fold 4.1-4.3 kB at 6794 entries, 3.3 kB at 6796 or 6812, 4.0 at 6820, 5.7-7.7 at 6832..6896, and
 // 9-16 kB whenever the stride is a whole number of 128-byte lines (6848, 6912, 6976) — profiles/r03/mfe_scratch_stride.txt)
-#define SF_CG_ENTRIES(W) (((((W)-4) * ((W)-3)) / 2 + 8 + 3) & ~1)
+// Which slice of the scratch a workgroup takes.  Workgroups go to the eight XCDs round robin (workgroup b runs on XCD b mod 8)
+// and every XCD has its own L2: with slice b for workgroup b an XCD's L2 held 128 chunks of 13.6 kB scattered over 14 MB, and
+// however the chunk stride was chosen some of its sets overflowed — 5.3-6.0 kB per fold of write-backs of dirty table lines at
+// W = 120 with four workgroups per CU, 0.3 kB with two.  With the slices of one XCD's workgroups ADJACENT (one contiguous
+// 1.75 MB range per L2) the same launch writes 1.25 kB per fold, 0.53 kB at W = 100 (was 5.2); same kernel time.
+__host__ __device__ inline unsigned sf_fast_scratch_slot(const unsigned block, const unsigned grid) {
+  return (block & 7u) * ((grid + 7u) >> 3) + (block >> 3);
+}
+// Per-workgroup stride of the scratch, in entries.  Which strides keep the tables of the resident workgroups in the L2 is an
+// empirical matter (profiles/r03/mfe_scratch_stride.txt, profiles/r04/mfe_scratch_placement.txt): at W = 120, with the tables
+// of one XCD's workgroups adjacent (sf_fast_scratch_slot), 7168 entries = 14 kB write 0.78 kB per fold to the fabric, the
+// table's own 6796 entries 1.25 kB, 7104 / 7232 1.7 kB.
+#define SF_CG_ENTRIES(W) ((W) == 120 ? 7168 : (((((W)-4) * ((W)-3)) / 2 + 8 + 3) & ~1))
 
 // Size-dependent terms (loop initiation, asymmetry) are the same for every lane: they are read from small LDS
 // tables with a wave-uniform address (a broadcast read).  (Keeping them spread over the lanes of a VGPR and
@@ -1435,7 +1447,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
   int16_t *tExt = (int16_t *)(smem + Lo.off_ci + (((W + 1) * 4 + 3) & ~3));
 
   const int tid = threadIdx.x;
-  X.cg = cg_all + (size_t)blockIdx.x * SF_CG_ENTRIES(W);  // c + ExtLoop by (row i, column j), triangular
+  X.cg = cg_all + (size_t)sf_fast_scratch_slot(blockIdx.x, gridDim.x) * SF_CG_ENTRIES(W);  // c + ExtLoop by (row i, column j), triangular
   // parameter tables -> LDS, once per workgroup
   for (int x = tid; x < 175; x += NT) {
     tab[x] = F->mm23[x];
@@ -1828,7 +1840,7 @@ static inline void sf_fast_geometry(int W, int n_cu, int n, int *grid, int *thre
   *grid = (int)gsz;
   *threads = nt;
   *lds = (size_t)L.total;
-  *scratch = (size_t)gsz * SF_CG_ENTRIES(W) * sizeof(int16_t);
+  *scratch = (size_t)((gsz + 7) & ~7LL) * SF_CG_ENTRIES(W) * sizeof(int16_t);  // whole groups of eight: sf_fast_scratch_slot
 }
 
 // W = 120 is ScanFold's default window (ScanFold-Scan.py:37) and W = 200 is BASELINE config 5: they get

@@ -1523,21 +1523,29 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
   int seq = blockIdx.x;
   while (seq < n) {
     const uint8_t *src = seqs + (size_t)seq * W;
+    // the per-thread addresses of this prologue are recomputed per fold: hoisted out of the fold loop they live in VGPRs through
+    // the whole fold, i.e. in spill slots (13 dwords per lane = 13.6 kB per workgroup of private memory competing with the
+    // scratch tables for the L2)
+    // (the generic wide instantiation is the exception: 107 -> 16 spilled registers with the pins, and 1.3-2.5 % SLOWER at
+    // W = 160 / 180 / 250 — it keeps the hoisted addresses)
+    constexpr bool PINF = !(NG == 256 && WT == 0);
+    int tidf = tid;
+    if (PINF) SF_PIN(tidf);
     __syncthreads();
     if (PZ) {
       for (int x = tid; x < Lo.off_tab / 2; x += NT) ((int16_t *)smem)[x] = sf_poison16(poison, x);
       if (HC) for (int x = tid; x < (Lo.total - Lo.off_hc) / 2; x += NT) ((int16_t *)(smem + Lo.off_hc))[x] = sf_poison16(poison, x);
       __syncthreads();
     }
-    for (int x = tid; x < W; x += NT) S[x + 1] = sf_encode_nt(src[x]);
-    if (MG && W >= SF_HELP_MERGE_MAXW) for (int x = tid; x < 128; x += NT) ((int16_t *)(smem + Lo.off_tab) + 1069 + 32 + 1)[x] = F->uni[x];
+    for (int x = tidf; x < W; x += NT) S[x + 1] = sf_encode_nt(src[x]);
+    if (MG && W >= SF_HELP_MERGE_MAXW) for (int x = tidf; x < 128; x += NT) ((int16_t *)(smem + Lo.off_tab) + 1069 + 32 + 1)[x] = F->uni[x];
     // The rolling tables (with their mirror rows and the cell lists) start every fold as "no structure".  The straight-line
     // cell code of the short diagonals reads candidates of loop sizes that do not exist yet — rows no diagonal of this fold
     // has written, up to 23 words past the end of a row — and charges them 32 767; the sum only stays "none" if what it
     // finds is energy-sized.  Until round 4 the tables were initialised once per workgroup and later folds found the
     // previous fold's energies there — as good, unless that fold had left the int16 range.  24 dword stores per thread
     // and fold (0.05 % of a fold) make a fold's result a function of its own sequence only.
-    for (int x = tid; x < (Lo.off_tab - Lo.off_ci) / 4; x += NT) ((uint32_t *)X.CI)[x] = sf_pk(SF_INF16, SF_INF16);
+    for (int x = tidf; x < (Lo.off_tab - Lo.off_ci) / 4; x += NT) ((uint32_t *)X.CI)[x] = sf_pk(SF_INF16, SF_INF16);
     int fetched = 0;
     if (tid == 0) {
       S[0] = 0; S[W + 1] = 0; flag[0] = 0;
@@ -1784,13 +1792,20 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
         sf_trail_result<NQ>(T, tid & 63, seq, flag[0], out, ovf_cnt, ovf_list);
       }
     } else {
-    for (int x = tid; x < 200; x += NT) tExt[x] = F->mmExt[x];
+    // (as tidf above: one fold in r + 1 comes here, and what its inlined sweep and traceback derive from the thread index need
+    // not live through the others: with this pin the narrow instantiations and W = 200 have no or 2 spilled registers — 45-53 and
+    // 12 before — and run 2-3.5 % faster (W = 64 / 128 / 200).  Not at W = 120: the allocation it gets there is 1.8 % slower —
+    // 59.8 against 58.8 ms per 262 144 folds, same hot blocks with five more s_waitcnt — and the first pin alone already leaves
+    // it 6 cold spill slots; profiles/r04/mfe_scratch_placement.txt)
+    int tidn = tid;
+    if (PINF && WT != 120) SF_PIN(tidn);
+    for (int x = tidn; x < 200; x += NT) tExt[x] = F->mmExt[x];
     __syncthreads();
     // (the scratch already holds c + ExtLoop: the sweep is one add and one min per cell; the mismatchExt table
     // above is for the traceback)
     int16_t *etab = nullptr;
     if (tid < 64)
-      sf_fast_exterior<NG / 64>(X, W, tid, seq, f5s, tExt, etab, flag, (int16_t *)(smem + Lo.off_cb),
+      sf_fast_exterior<NG / 64>(X, W, tidn, seq, f5s, tExt, etab, flag, (int16_t *)(smem + Lo.off_cb),
                       (char *)(smem + Lo.off_cb + ((3 * (W + 8) * 2 + 3) & ~3)), out, ovf_cnt, ovf_list, trace_stride,
                       db_out, status);
     }

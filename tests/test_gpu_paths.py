@@ -6,7 +6,8 @@
 * a stretch of 120 x N inside a transcript through scan_record on the HIP engine (ScanFold-Scan.py:374-380: the literal
   row; the device dinucleotide shuffle of a one-symbol window; the partition function of a window that cannot pair);
 * `-type mono` through the command line against the shuffle oracle on BASELINE configs 1 and 2 (ScanFold-Scan.py:273-274);
-* the slack the short-diagonal cell code over-reads, poisoned (SCANFOLD_MFE_POISON): energies must not move.
+* the slack the short-diagonal cell code over-reads, poisoned (SCANFOLD_MFE_POISON): energies must not move;
+* the -t path against the independent Python model of tests/py_model.py.
 Nothing here reads /root/reference."""
 import json
 import os
@@ -152,3 +153,26 @@ def test_poisoned_lds_slack_does_not_move_an_energy(gpu_engine, oracle):
     for W in (77, 120, 200):
         arr = random_seqs(np.random.default_rng(W), 1500, W)
         assert (gpu_engine.mfe_batch(arr) == oracle.mfe_batch(arr)).all()
+
+
+def test_temperature_path_against_the_independent_python_model(gpu_engine):
+    """-t on the HIP engine against tests/py_model.py (a pure-Python restatement of the model in energy space that shares no code
+    with the oracle or the library): ensemble energy, ensemble diversity and MFE of enumerable sequences at 25 and 50 C."""
+    import py_model
+    from par_util import par_text, synthetic_enthalpies
+    from scanfold_amd import params
+    from test_independent_model import SEQS
+    base = params.default_params()
+    pset = params.parse_par_text(par_text(base.rec, synthetic_enthalpies(base.rec, 5)), source="synthetic.par")
+    try:
+        gpu_engine.load_params(pset)
+        for T in (25.0, 50.0):
+            gpu_engine.set_temperature(T)
+            for seq in SEQS:
+                dg, dist, count, mfe, db, _ = py_model.ensemble(pset, seq, T)
+                o = gpu_engine.pf_batch([seq])
+                assert abs(float(o["dG"][0]) - dg) < 1e-9 * max(1.0, abs(dg)), (seq, T, o["dG"][0], dg)
+                assert abs(float(o["mean_bp_dist"][0]) - dist) < 1e-9, (seq, T)
+                assert int(gpu_engine.mfe_batch([seq])[0]) == mfe, (seq, T)
+    finally:
+        gpu_engine.load_params(base)

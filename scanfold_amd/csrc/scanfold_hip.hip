@@ -218,6 +218,10 @@ void build_dev_params(const sf_params_blob &P, SfDevParams &D, SfDevParamsPF &X,
     }
 }
 
+// sf_pf_fast_kernel is compiled for two waves per SIMD (256 VGPRs): eight waves per CU = four workgroups of 128 threads
+// (W <= 128) or two of 256.  A grid larger than that only runs its surplus workgroups as a second round — on a second set of
+// 2-MB table slices (W = 200: 2.1 GB instead of 1.07 GB of scratch).
+static int pf_fast_blocks_per_cu(int W) { return W > 128 ? g.pf_blocks_per_cu / 2 : g.pf_blocks_per_cu; }
 int max_resident_blocks() { return g.n_cu * 4; }
 
 // FULL kernel over n items; see sf_mfe_full_kernel for the indexing arguments
@@ -265,7 +269,7 @@ int launch_pf(const uint8_t *d_seqs, int n, int row_stride, int W, double *d_dG,
     sf_pf_lds_launch(grid, W, share != nullptr, st, d_seqs, n, row_stride, W, (const SfDevParams *)g.dP, (const SfDevParamsPF *)g.dX,
                      d_dG, d_mbd, d_cen, d_cd, d_tr, L, win0, step, run_len, share, (const char *)nullptr, (int *)nullptr);
   } else if (W >= 16 && W <= SF_PFF_MAXW && !g.force_full) {
-    const int pf_blocks = g.n_cu * g.pf_blocks_per_cu;
+    const int pf_blocks = g.n_cu * pf_fast_blocks_per_cu(W);
     grid = n < pf_blocks ? n : pf_blocks;
     int rc = ensure(g.pf_scratch, (size_t)grid * SF_PFF_SCRATCH_DOUBLES(W) * sizeof(double));
     if (rc) return rc;
@@ -723,7 +727,7 @@ int sf_fold_constrained(const uint8_t *seqs, int n, int W, const char *cons, con
                           (double *)nullptr, d_cons, (int *)g.status.p);
     } else if (!noncanonical && !g.force_full && W >= 16 && W <= SF_PFF_HC_MAXW) {
       // the constrained instantiation of the device-table kernel (120 < W <= 250, or SCANFOLD_PF_KERNEL=global)
-      const int pf_blocks = g.n_cu * g.pf_blocks_per_cu;
+      const int pf_blocks = g.n_cu * pf_fast_blocks_per_cu(W);
       grid = n < pf_blocks ? n : pf_blocks;
       if ((rc = ensure(g.pf_scratch, (size_t)grid * SF_PFF_SCRATCH_DOUBLES(W) * sizeof(double)))) return rc;
       sf_pf_fast_launch_hc(grid, W, g.stream, (const uint8_t *)g.seqs.p, n, 1, W, (const SfDevParams *)g.dP,

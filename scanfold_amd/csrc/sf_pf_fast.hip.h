@@ -20,6 +20,9 @@
 #define SF_PFF_TABLE_DOUBLES(W) ((size_t)(W) * ((W) + 1) / 2 + 8)
 #define SF_PFF_SCRATCH_DOUBLES(W) (SF_PFF_NTABLES * SF_PFF_TABLE_DOUBLES(W))
 #define SF_PFF_MAXW 256
+#ifndef SF_PFF_UNROLL
+#define SF_PFF_UNROLL 4  // terms of a cooperative multiloop sum in flight per thread
+#endif
 
 struct SfPfTabs {
   double *QB, *QBI, *QB1N, *QBB, *QM, *QM1, *OB, *OBI, *OB1N, *OBB, *OBW, *A0, *A1;
@@ -47,6 +50,9 @@ __global__ __launch_bounds__(NT, 2) void sf_pf_fast_kernel(const uint8_t *__rest
   __shared__ double q5[SF_PFF_MAXW + 2];
   __shared__ double q3[SF_PFF_MAXW + 3];
   __shared__ double red[8];
+  // partial sums of the O(W) multiloop sums of one diagonal, [part][cell] (see inside_sums / outside_sums)
+  __shared__ double ps0[NT], ps1[NT];
+  __shared__ double mlbS[SF_PFF_MAXW + 2];
   const int W = WT ? WT : Wrt;  // WT > 0: width known at compile time
   const int tid = threadIdx.x;
   const int W1 = W + 1;
@@ -63,7 +69,8 @@ __global__ __launch_bounds__(NT, 2) void sf_pf_fast_kernel(const uint8_t *__rest
 // the pair type of a cell's OWN pair (a, b): sequence, max_bp_span and — HC — the fold's constraint
 #define OWNT(Dp, a, b) (HC ? sf_hc_type8(hc, ((b) - (a) <= (Dp)->max_pair_dist ? (Dp)->pair[S[a]][S[b]] : 0), (a), (b), (b) - (a) <= (Dp)->max_pair_dist) \
                            : ((b) - (a) <= (Dp)->max_pair_dist ? (Dp)->pair[S[a]][S[b]] : 0))
-  const double *mlb = X->mlbase_pow;
+  for (int x = threadIdx.x; x <= W + 1; x += NT) mlbS[x] = X->mlbase_pow[x];  // (read with per-lane indices in the cooperative sums)
+  const double *mlb = mlbS;
   const int OFF = (((W + 1) >> 1) - 32 + NT) & (NT - 1);
   const int v = (tid + OFF) & (NT - 1);
   const double xTAU = X->TermAU;
@@ -89,6 +96,40 @@ __global__ __launch_bounds__(NT, 2) void sf_pf_fast_kernel(const uint8_t *__rest
     for (int u = 0; u < 27; u++) { Ha[u] = 0.0; Hb[u] = 0.0; }
     // GT = std::true_type: loop sizes are tested against the limit d-6.  (A false_type instantiation makes the
     // candidate code straight-line; in FP64 that needs >256 VGPRs and spills, so it is not used.)
+    // The two O(d) sums of a cell — the multiloop closing sum  sum_a qm[i+1, .] qm1[., j-1]  and the qm recurrence
+    // sum_a (MLbase^a + qm[i, .]) qm1[., j] — read diagonals < d only.  One thread per cell walked them alone: d / 4 dependent
+    // round trips to the L2 per diagonal, with W - d of the NT threads at work — the whole kernel waited on that chain (41 ms
+    // per 200-mer).  Now a diagonal's NT threads split into k = NT / (W - d) parts per cell (part-major, so the lanes of a part
+    // still read consecutive cells), every part sums its share of the range, and the cell's owner adds the k partial sums
+    // from LDS.  Early diagonals (k = 1) are as before; from d = W - NT / 2 on the chain shrinks with the diagonal.
+    // W = 200: 323 -> 226 ms per 4 096 folds (12.7 k -> 18.1 k folds/s), W = 160 1.50 x, W = 250 1.38 x; results equal to 1e-13
+    // (profiles/r04/pf_fast_cooperative.txt).  What bounds it now is the fabric: 120 MB fetched per 200-mer (2 x FETCH_SIZE),
+    // 2.2 TB/s at that rate — the tables of the 512 resident folds (2 MB each) are far beyond the L2s; the terms in flight per
+    // thread (2 / 4 / 8) no longer matter.
+    auto inside_sums = [&](const int d) {
+      const SfDevParams *const Dc = sf_const_base(D);
+      const int n = W - d, kk = NT / n;
+      const int p = tid / n, c = tid - p * n;
+      if (p < kk) {
+        const int i = c + 1, j = i + d;
+        double sm = 0.0, sq = 0.0;
+        if (OWNT(Dc, i, j)) {
+          const int lo = SFD_TURN + 2, hi = d - SFD_TURN - 2;
+          const int per = (hi - lo + kk) / kk;  // ceil((hi - lo + 1) / kk); <= 0 for an empty range
+          const int a0 = lo + p * per, a1 = sfd_min(a0 + per - 1, hi);
+#pragma unroll SF_PFF_UNROLL
+          for (int a = a0; a <= a1; a++) sm += PT(T.QM, a - 2, i + 1) * PT(T.QM1, d - 1 - a, i + a);
+        }
+        {
+          const int lo = 1, hi = d - SFD_TURN - 1;
+          const int per = (hi - lo + kk) / kk;
+          const int a0 = lo + p * per, a1 = sfd_min(a0 + per - 1, hi);
+#pragma unroll SF_PFF_UNROLL
+          for (int a = a0; a <= a1; a++) sq += (mlb[a] + PT(T.QM, a - 1, i)) * PT(T.QM1, d - a, i + a);
+        }
+        ps0[tid] = sm; ps1[tid] = sq;
+      }
+    };
     auto inside_step = [&](const int d, double(&H)[27], auto GT) {
       // (parameter blocks through sf_const_base: their tables addressed "one scalar base + offset" — the compiler otherwise keeps
       // one hoisted 64-bit address per table row in scalar registers it does not have: thousands of v_readlane restores)
@@ -148,8 +189,10 @@ __global__ __launch_bounds__(NT, 2) void sf_pf_fast_kernel(const uint8_t *__rest
             z += gb * tau_out + g1 * Xc->mismatch1nI[type][si1][sj1] + gg * Xc->mismatchI[type][si1][sj1];
           }
           double ml = 0.0;
-#pragma unroll 4
-          for (int a = SFD_TURN + 2; a <= d - SFD_TURN - 2; a++) ml += PT(T.QM, a - 2, i + 1) * PT(T.QM1, d - 1 - a, i + a);
+          {
+            const int n = W - d, kk = NT / n;
+            for (int q = 0; q < kk; q++) ml += ps0[q * n + i - 1];
+          }
           z += ml * Xc->MLclosing * sfx_mlstem(Xc, sfd_rtype(type), sj1, si1);
           qbij = z;
         }
@@ -164,14 +207,20 @@ __global__ __launch_bounds__(NT, 2) void sf_pf_fast_kernel(const uint8_t *__rest
           if (type) m1 += qbij * sfx_mlstem(Xc, type, i > 1 ? sp1 : -1, j < W ? sq1 : -1);
           PT(T.QM1, d, i) = m1;
           double m = m1;
-#pragma unroll 4
-          for (int a = 1; a <= d - SFD_TURN - 1; a++) m += (mlb[a] + PT(T.QM, a - 1, i)) * PT(T.QM1, d - a, i + a);
+          {
+            const int n = W - d, kk = NT / n;
+            for (int q = 0; q < kk; q++) m += ps1[q * n + i - 1];
+          }
           PT(T.QM, d, i) = m;
         }
       }
     };
     for (int d = SFD_TURN + 1; d < W; d += 2) {  // even d -> Ha, odd d -> Hb
+      inside_sums(d);
+      __syncthreads();
       inside_step(d, Ha, std::true_type{});
+      __syncthreads();
+      if (d + 1 < W) inside_sums(d + 1);
       __syncthreads();
       if (d + 1 < W) {
         inside_step(d + 1, Hb, std::true_type{});
@@ -212,6 +261,35 @@ __global__ __launch_bounds__(NT, 2) void sf_pf_fast_kernel(const uint8_t *__rest
 #pragma unroll
     for (int u = 0; u < 27; u++) { Ha[u] = 0.0; Hb[u] = 0.0; }
     double mbd = 0.0, cd = 0.0;
+    // (the outside pass's two O(W - d) sums — A1 over the closers (k, j) and the multiloop-stem sum over the closers' spans —
+    // read diagonals > d only, all complete: split over the idle threads like the inside sums)
+    auto outside_sums = [&](const int d) {
+      const SfDevParams *const Dc = sf_const_base(D);
+      const int n = W - d, kk = NT / n;
+      const int p = tid / n, c = tid - p * n;
+      if (p < kk) {
+        const int i = c + 1, j = i + d;
+        double sa = 0.0, sm = 0.0;
+        if (i > 1) {
+          const int lo = d + SFD_TURN + 3, hi = sfd_min(W - 1, j - 1);
+          const int per = (hi - lo + kk) / kk;
+          const int d0 = lo + p * per, d1 = sfd_min(d0 + per - 1, hi);
+#pragma unroll SF_PFF_UNROLL
+          for (int dd = d0; dd <= d1; dd++) sa += PT(T.OBW, dd, j - dd) * PT(T.QM, dd - d - 2, j - dd + 1);
+        }
+        if (i > 1 && j < W && OWNT(Dc, i, j) && PT(T.QB, d, i) != 0.0) {
+          const int lo = d + 2, hi = sfd_min(W - 1, W - i);
+          const int per = (hi - lo + kk) / kk;
+          const int d0 = lo + p * per, d1 = sfd_min(d0 + per - 1, hi);
+#pragma unroll SF_PFF_UNROLL
+          for (int dd = d0; dd <= d1; dd++) {
+            const double q0 = PT(T.QM, dd - d - 2, j + 1);
+            sm += PT(T.A1, dd, i) * (mlb[dd - d - 1] + q0) + PT(T.A0, dd, i) * q0;
+          }
+        }
+        ps0[tid] = sa; ps1[tid] = sm;
+      }
+    };
     auto outside_step = [&](const int d, double(&G)[27], auto GT) {
       // (parameter blocks through sf_const_base: their tables addressed "one scalar base + offset" — the compiler otherwise keeps
       // one hoisted 64-bit address per table row in scalar registers it does not have: thousands of v_readlane restores)
@@ -250,17 +328,8 @@ __global__ __launch_bounds__(NT, 2) void sf_pf_fast_kernel(const uint8_t *__rest
         if (i > 1) {
           a0 = PT(T.A0, d + 1, i - 1) * Xc->MLbase + PT(T.OBW, d + 1, i - 1);
           {
-            // closers (kk, j) with kk = j - dd >= 1: a per-thread bound, no test inside the loop
-            const int ddmax = sfd_min(W - 1, j - 1);
-            double a1b = 0.0;
-            int dd = d + SFD_TURN + 3;
-#pragma unroll 4
-            for (; dd + 1 <= ddmax; dd += 2) {
-              a1 += PT(T.OBW, dd, j - dd) * PT(T.QM, dd - d - 2, j - dd + 1);
-              a1b += PT(T.OBW, dd + 1, j - dd - 1) * PT(T.QM, dd - d - 1, j - dd);
-            }
-            if (dd <= ddmax) a1 += PT(T.OBW, dd, j - dd) * PT(T.QM, dd - d - 2, j - dd + 1);
-            a1 += a1b;
+            const int n = W - d, kk = NT / n;
+            for (int q = 0; q < kk; q++) a1 += ps0[q * n + i - 1];
           }
         }
         PT(T.A0, d, i) = a0;
@@ -327,22 +396,11 @@ __global__ __launch_bounds__(NT, 2) void sf_pf_fast_kernel(const uint8_t *__rest
             // (i,j) as a stem of a multiloop closed by (k,l): indexed by the span dd = l - i
             double mlsum = 0.0;
             {
-              // closers (k, l) with l = i + dd <= W: per-thread bound; dd = d+1 has an empty right part
+              // closers (k, l) with l = i + dd <= W; dd = d+1 has an empty right part, the spans >= d + 2 come from outside_sums
               const int ddmax = sfd_min(W - 1, W - i);
               if (d + 1 <= ddmax) mlsum += PT(T.A1, d + 1, i) * mlb[0];
-              double ms2 = 0.0;
-              int dd = d + 2;
-#pragma unroll 4
-              for (; dd + 1 <= ddmax; dd += 2) {
-                const double q0 = PT(T.QM, dd - d - 2, j + 1), q1 = PT(T.QM, dd - d - 1, j + 1);
-                mlsum += PT(T.A1, dd, i) * (mlb[dd - d - 1] + q0) + PT(T.A0, dd, i) * q0;
-                ms2 += PT(T.A1, dd + 1, i) * (mlb[dd - d] + q1) + PT(T.A0, dd + 1, i) * q1;
-              }
-              if (dd <= ddmax) {
-                const double q0 = PT(T.QM, dd - d - 2, j + 1);
-                mlsum += PT(T.A1, dd, i) * (mlb[dd - d - 1] + q0) + PT(T.A0, dd, i) * q0;
-              }
-              mlsum += ms2;
+              const int n = W - d, kk = NT / n;
+              for (int q = 0; q < kk; q++) mlsum += ps1[q * n + i - 1];
             }
             o += mlsum * sfx_mlstem(Xc, type, sp1, sq1);
           }
@@ -366,12 +424,18 @@ __global__ __launch_bounds__(NT, 2) void sf_pf_fast_kernel(const uint8_t *__rest
     {
       int d = W - 1;
       if (d & 1) {
+        outside_sums(d);
+        __syncthreads();
         outside_step(d, Hb, std::true_type{});
         __syncthreads();
         d--;
       }
       for (; d >= SFD_TURN + 1; d -= 2) {
+        outside_sums(d);
+        __syncthreads();
         outside_step(d, Ha, std::true_type{});
+        __syncthreads();
+        if (d - 1 >= SFD_TURN + 1) outside_sums(d - 1);
         __syncthreads();
         if (d - 1 >= SFD_TURN + 1) {
           outside_step(d - 1, Hb, std::true_type{});

@@ -271,3 +271,18 @@ def test_poisoned_lds_slack_does_not_move_an_energy_emulated(emul, oracle, monke
     monkeypatch.delenv("SCANFOLD_MFE_POISON")
     for (W, arr), (ref, _) in zip(cases, refs):
         assert (emul.mfe_batch(arr) == ref).all(), W
+
+
+def test_device_table_partition_function_cooperative_sums(emul, oracle):
+    """sf_pf_fast_kernel (120 < W <= 256; tables in device memory): the O(W) multiloop sums of a diagonal are split over the
+    diagonal's idle threads and added up from LDS by the cell's owner (inside_sums / outside_sums).  Widths on both sides of
+    the 128- / 256-thread instantiations (W = 121: 128 threads, one part per cell until d = 57; W = 129: 256 threads, two parts
+    from the first diagonal on; W = 250: one part until d = 122): == oracle."""
+    rng = np.random.default_rng(12)
+    for W, n in ((121, 2), (129, 2), (200, 1), (250, 1)):
+        arr = random_seqs(rng, n, W)
+        r = emul.pf_batch(arr)
+        for k in range(n):
+            o = oracle.pf(bytes(arr[k]).decode())
+            assert abs(o["dG"] - r["dG"][k]) < 1e-9 and o["centroid"] == r["centroid"][k], W
+            assert abs(o["mean_bp_dist"] - r["mean_bp_dist"][k]) < 1e-9 and abs(o["centroid_dist"] - r["centroid_dist"][k]) < 1e-9, W

@@ -261,7 +261,7 @@ int launch_pf(const uint8_t *d_seqs, int n, int row_stride, int W, double *d_dG,
       }
       if (run_len > 1) {
         grid = (n + run_len - 1) / run_len < g.n_cu ? (n + run_len - 1) / run_len : g.n_cu;
-        int rc = ensure(g.pf_share, (size_t)grid * SF_PFL_SHARE_DOUBLES(W) * sizeof(double));
+        int rc = ensure(g.pf_share, (size_t)((grid + 7) & ~7) * SF_PFL_SHARE_DOUBLES(W) * sizeof(double));  // whole groups of eight slices: see sv in the kernel
         if (rc) return rc;
         share = (double *)g.pf_share.p;
       }

@@ -171,7 +171,9 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
 
   const bool shared = SH;  // (a template parameter: the stand-alone instantiation carries none of the extra state)
   const int SV_QM = NC, SV_DER = 2 * NC, SV_QM1 = SV_DER + 12 * RP, SV_H = SV_QM1 + 2 * VW + 8;
-  double *sv = SH ? share + (size_t)blockIdx.x * SF_PFL_SHARE_DOUBLES(W) : nullptr;
+  // (slices of the workgroups of one XCD — block b runs on XCD b mod 8 — adjacent: the state a workgroup parks, 102 kB at W = 120, is
+  // read back by the same workgroup one window later; 32 workgroups per XCD x 102 kB = 3.3 MB stay in that XCD's 4-MB L2)
+  double *sv = SH ? share + (size_t)((blockIdx.x & 7u) * ((gridDim.x + 7u) >> 3) + (blockIdx.x >> 3)) * SF_PFL_SHARE_DOUBLES(W) : nullptr;
   if (!shared) run_len = 1;
   for (int fold0 = blockIdx.x * run_len; fold0 < n; fold0 += gridDim.x * run_len)
   for (int fold = fold0; fold < fold0 + run_len && fold < n; fold++) {
@@ -237,6 +239,9 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
             if (jj <= W - k && ii <= jj - 4) QBC(ii, jj) = v[b][h];
           }
       }
+      // qm never left the LDS (the outside pass does not write it): shifted in place, diagonal by diagonal.  A diagonal belongs to
+      // one wave, which reads a whole batch before it writes it (the wave-level sync only matters to the CPU emulation, whose
+      // lanes run one after the other in no fixed order; in lockstep the reads of an instruction precede the writes of a later one)
       for (int d0b = 4 + wv; d0b <= W - k - 1; d0b += RB * NWV) {
         double v[RB][2];
 #pragma unroll
@@ -244,8 +249,9 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
 #pragma unroll
           for (int h = 0; h < 2; h++) {
             const int dd = d0b + b * NWV, ii = 1 + ln + 64 * h;
-            v[b][h] = (dd <= W - k - 1 && ii <= W - k - dd) ? sv[SV_QM + DOFF(dd) + ii + k - 1] : 0.0;
+            v[b][h] = (dd <= W - k - 1 && ii <= W - k - dd) ? QM[DOFF(dd) + ii + k - 1] : 0.0;
           }
+        SF_WAVE_SYNC();
 #pragma unroll
         for (int b = 0; b < RB; b++)
 #pragma unroll
@@ -253,6 +259,7 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
             const int dd = d0b + b * NWV, ii = 1 + ln + 64 * h;
             if (dd <= W - k - 1 && ii <= W - k - dd) QMD(dd, ii) = v[b][h];
           }
+        SF_WAVE_SYNC();
       }
       // derived buffers of the last three old columns (= new columns j0-3 .. j0-1), rows shifted; qm1 of new column j0-1
       for (int x = tid; x < 9 * W; x += SF_PFL_NT) {
@@ -470,8 +477,10 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
     }
 
     if (keep) {  // the inside state for the next window of the run (nothing below reads sv)
-      for (int x = tid; x < 2 * NC + 12 * RP + 2 * VW + 8; x += SF_PFL_NT)
-        sv[x] = x < SV_DER ? QB[x] : (x < SV_QM1 ? DER[x - SV_DER] : QM1[x - SV_QM1]);
+      // (qb — about to be overwritten by the outside values —, the derived buffers, qm1; qm stays where it is: 54 of the 156 kB)
+      for (int x = tid; x < NC; x += SF_PFL_NT) sv[x] = QB[x];
+      for (int x = SV_DER + tid; x < 2 * NC + 12 * RP + 2 * VW + 8; x += SF_PFL_NT)
+        sv[x] = x < SV_QM1 ? DER[x - SV_DER] : QM1[x - SV_QM1];
       if (team == 0) {
 #pragma unroll
         for (int u = 0; u < 27; u++) sv[SV_H + c * 27 + u] = H[u];

@@ -56,4 +56,7 @@ def test_calibrated_unit_fractions_from_the_committed_rates():
     cnt = json.load(open(os.path.join(ROOT, "profiles", "r04", "mfe_counters.json")))
     assert cnt["folds"] == 3017981 and cnt["launches"] == 1
     assert abs(cnt["secondary"]["valu_insts_per_fold"] / sec["valu_insts_per_fold"] - 1) < 0.02
-    assert abs(cnt["hbm_bytes_per_launch"] / line["roofline"]["traffic"] - 1) < 0.05
+    # (two sets of counter passes of the same scan; since the scratch tables stay in the L2 — round 4 — the traffic is a few
+    # hundred bytes per fold of capacity evictions and varies by +-10 % between passes; it was 5.5 kB per fold before)
+    assert abs(cnt["hbm_bytes_per_launch"] / line["roofline"]["traffic"] - 1) < 0.25
+    assert cnt["hbm_bytes_per_launch"] < 2.5e9 and line["roofline"]["traffic"] < 2.5e9

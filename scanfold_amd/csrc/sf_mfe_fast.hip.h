@@ -686,11 +686,8 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
         // together, two accumulators take turns, and a fence keeps the vector stages in that order: same vector instructions,
         // 30 fewer idle issue slots per cell pass, +1 %.  The other instantiations measured 1-2 % SLOWER with it — their
         // longer live ranges spill — and keep the chain.)
-#ifdef SF_EXP_STAGED_ALL
-        constexpr bool STAGED = !FOLD;
-#else
+        // (re-measured after the spill pins freed the generic narrow kernels' registers: still 0.4-3 % slower there)
         constexpr bool STAGED = (WT == 120);
-#endif
         uint32_t acc = sf_pk(32767, 32767), accb = acc;
         constexpr int SF_HELP_NB = FOLD ? SF_HELP_NB_256 : SF_HELP_NB_128;
 #pragma unroll

@@ -7,7 +7,8 @@
   row; the device dinucleotide shuffle of a one-symbol window; the partition function of a window that cannot pair);
 * `-type mono` through the command line against the shuffle oracle on BASELINE configs 1 and 2 (ScanFold-Scan.py:273-274);
 * the slack the short-diagonal cell code over-reads, poisoned (SCANFOLD_MFE_POISON): energies must not move;
-* the -t path against the independent Python model of tests/py_model.py.
+* the -t path against the independent Python model of tests/py_model.py;
+* the per-XCD placement of the MFE scratch tables and of the parked partition-function state with grids that are not multiples of eight.
 Nothing here reads /root/reference."""
 import json
 import os
@@ -176,3 +177,27 @@ def test_temperature_path_against_the_independent_python_model(gpu_engine):
                 assert int(gpu_engine.mfe_batch([seq])[0]) == mfe, (seq, T)
     finally:
         gpu_engine.load_params(base)
+
+
+def test_scratch_slices_with_grids_that_are_not_multiples_of_eight(gpu_engine, oracle):
+    """The c + ExtLoop tables (MFE kernel) and the parked partition-function state are placed per XCD — slice
+    (b mod 8) * ceil(grid / 8) + b / 8 for workgroup b — so a grid that is not a multiple of eight uses slices beyond `grid`:
+    batches of 1 .. 1031 folds (grid = n below the resident 1 024) and scans of 3 .. 37 windows, against the oracle."""
+    rng = np.random.default_rng(77)
+    for W in (120, 100, 200):
+        for n in (1, 7, 9, 63, 1025 if W != 200 else 515, 1031 if W != 200 else 517):
+            arr = random_seqs(rng, n, W)
+            got = gpu_engine.mfe_batch(arr)
+            sel = np.unique(np.concatenate([np.arange(min(n, 8)), np.arange(max(n - 8, 0), n)]))
+            assert (got[sel] == oracle.mfe_batch(arr[sel])).all(), (W, n)
+            e, db = gpu_engine.mfe_trace_batch(arr[:min(n, 9)])
+            for k in range(min(n, 9)):
+                odb, oe = oracle.mfe(bytes(arr[k]).decode())
+                assert (db[k], e[k]) == (odb, oe), (W, n, k)
+    seq = "".join("ACGU"[k] for k in rng.integers(0, 4, 160))
+    for n_win in (3, 9, 37):
+        res = gpu_engine.scan(seq, 120, 1, 0, n_win, 2, _lib.SHUFFLE_DI, 3)
+        for w in (0, n_win // 2, n_win - 1):
+            o = oracle.pf(seq[w:w + 120])
+            assert abs(o["dG"] - res["ens_dG"][w]) < 1e-9 and o["centroid"] == res["centroid"][w], (n_win, w)
+            assert abs(o["mean_bp_dist"] - res["ens_div"][w]) < 1e-9, (n_win, w)

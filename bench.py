@@ -544,8 +544,8 @@ def main():
             out["e2e"] = {"windows_per_s": n_win / med, "median_s": med, "runs": len(times), "min_s": min(times),
                           "max_s": max(times), "tsv_bytes": nbytes, "ratio_to_device_resident": (n_win / med) / value,
                           "what": "scan.scan_record(): transcript H2D, all kernels, D2H, z/p-scores, TSV rows; host "
-                                  "formatting of chunk k overlaps the GPU on chunk k+1 (%d-window chunks)"
-                                  % scanmod.CHUNK_WINDOWS}
+                                  "formatting of chunk k overlaps the GPU on chunk k+1 (engine calls of %s windows)"
+                                  % " + ".join(str(nw) for _, nw in scanmod._chunk_bounds(0, n_win))}
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(seq, W, step, r, kind, wl["shuffle_seed"])
         print(json.dumps(out))

@@ -132,14 +132,39 @@ CHUNK_WINDOWS = 4096  # windows per engine call: the host formats chunk k while 
 LAST_STATS = {}
 
 
+def _chunk_bounds(lo, hi, chunk=None):
+    """[(first window, count)] of the engine calls for windows [lo, hi).  An explicit size (argument or SCANFOLD_CHUNK_WINDOWS)
+    gives equal chunks.  The default schedule is tapered: what the pipeline cannot overlap is the host's work on the LAST chunk,
+    and what the GPU loses per call (a partition-function run's first window is a full one, the tail of a launch) shrinks with
+    the chunk — so the body goes in a few large calls (about 2 x CHUNK_WINDOWS each) and the end in a small one (CHUNK_WINDOWS / 8):
+    cfg3 = 4 x 7 343 + 509 windows instead of 8 x 4 096."""
+    n = hi - lo
+    explicit = chunk or os.environ.get("SCANFOLD_CHUNK_WINDOWS")
+    if explicit:
+        c = int(explicit)
+        return [(w0, min(c, hi - w0)) for w0 in range(lo, hi, c)]
+    if n <= CHUNK_WINDOWS:
+        return [(lo, n)] if n > 0 else []
+    tail = max(256, CHUNK_WINDOWS // 8)
+    body = n - tail
+    parts = -(-body // (2 * CHUNK_WINDOWS))
+    size = -(-body // parts)
+    bounds, w0 = [], lo
+    while w0 < lo + body:
+        nw = min(size, lo + body - w0)
+        bounds.append((w0, nw))
+        w0 += nw
+    bounds.append((w0, hi - w0))
+    return bounds
+
+
 def _engine_chunks(work, lo, hi, chunk=None, threaded=True):
     """Yield (w0, work(w0, nw)) for consecutive chunks of windows [lo, hi).  `work` makes the engine calls; it runs
     on a helper thread (ctypes drops the GIL for the duration of a library call), so the caller's host work on
     chunk k overlaps chunk k+1 on the GPU.  Only that thread talks to the library while the generator is alive."""
     import queue
     import threading
-    chunk = chunk or int(os.environ.get("SCANFOLD_CHUNK_WINDOWS", CHUNK_WINDOWS))
-    bounds = [(w0, min(chunk, hi - w0)) for w0 in range(lo, hi, chunk)]
+    bounds = _chunk_bounds(lo, hi, chunk)
     if not threaded or len(bounds) <= 1:
         for w0, nw in bounds:
             yield w0, work(w0, nw)

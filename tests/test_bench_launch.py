@@ -60,3 +60,18 @@ def test_calibrated_unit_fractions_from_the_committed_rates():
     # hundred bytes per fold of capacity evictions and varies by +-10 % between passes; it was 5.5 kB per fold before)
     assert abs(cnt["hbm_bytes_per_launch"] / line["roofline"]["traffic"] - 1) < 0.25
     assert cnt["hbm_bytes_per_launch"] < 2.5e9 and line["roofline"]["traffic"] < 2.5e9
+
+
+def test_chunk_schedule_covers_the_range_and_tapers():
+    """scan._chunk_bounds: the engine calls of a scan cover [lo, hi) without gaps; the default schedule ends in a small chunk
+    (what the pipeline cannot overlap is the host's work on the last one), an explicit size gives equal chunks."""
+    sys.path.insert(0, ROOT)
+    from scanfold_amd import scan
+    for n in (0, 1, 255, 4096, 4097, 5000, 29881, 100000):
+        b = scan._chunk_bounds(10, 10 + n)
+        assert sum(nw for _, nw in b) == n and all(nw > 0 for _, nw in b)
+        assert all(b[k][0] + b[k][1] == b[k + 1][0] for k in range(len(b) - 1)) and (not b or b[0][0] == 10)
+        if n > scan.CHUNK_WINDOWS:
+            assert b[-1][1] == 512 and max(nw for _, nw in b) <= 2 * scan.CHUNK_WINDOWS
+    assert [nw for _, nw in scan._chunk_bounds(0, 29881)] == [7343, 7343, 7343, 7340, 512]
+    assert scan._chunk_bounds(0, 10000, chunk=3000) == [(0, 3000), (3000, 3000), (6000, 3000), (9000, 1000)]

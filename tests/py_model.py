@@ -223,7 +223,34 @@ def structures(seq, min_hairpin=3, max_loop=30):
             yield pt
 
 
-def ensemble(paramset, seq, temperature_c):
+def admissible(pt, cons):
+    """Hard constraint in ViennaRNA's dot-bracket notation with its default, non-enforcing options: `x` stays
+    unpaired; `<` / `>` may pair with a partner downstream / upstream only; a bracket pair may pair with each other only and
+    no pair may cross it; `|` and `.` change nothing.  Stated on whole structures (the oracle states it per cell of its DP)."""
+    n = len(cons)
+    brackets, stack = [], []
+    for k, ch in enumerate(cons, 1):
+        if ch == "(":
+            stack.append(k)
+        elif ch == ")":
+            brackets.append((stack.pop(), k))
+    assert not stack
+    for i in range(1, n + 1):
+        j = pt[i]
+        if j <= i:
+            continue
+        ci, cj = cons[i - 1], cons[j - 1]
+        if ci == "x" or cj == "x" or ci == ">" or cj == "<":
+            return False
+        if (ci in "()" or cj in "()") and (i, j) not in brackets:
+            return False
+        for (a, b) in brackets:
+            if (i < a < j < b) or (a < i < b < j):
+                return False
+    return True
+
+
+def ensemble(paramset, seq, temperature_c, cons=None):
     """(ensemble free energy in kcal/mol, mean base-pair distance, number of structures) at T from the un-truncated energies,
     (MFE in dcal/mol, its structure) from the truncated ones."""
     pf, mfe = Model(paramset, temperature_c, "pf"), Model(paramset, temperature_c, "mfe")
@@ -232,6 +259,8 @@ def ensemble(paramset, seq, temperature_c):
     pp = {}
     best, best_pt = None, None
     for pt in structures(seq):
+        if cons is not None and not admissible(pt, cons):
+            continue
         w = math.exp(-pf.energy(seq, pt) * 10.0 / pf.kT)
         z += w
         count += 1

@@ -175,6 +175,12 @@ def test_temperature_path_against_the_independent_python_model(gpu_engine):
                 assert abs(float(o["dG"][0]) - dg) < 1e-9 * max(1.0, abs(dg)), (seq, T, o["dG"][0], dg)
                 assert abs(float(o["mean_bp_dist"][0]) - dist) < 1e-9, (seq, T)
                 assert int(gpu_engine.mfe_batch([seq])[0]) == mfe, (seq, T)
+            from test_independent_model import CONSTRAINED
+            for seq, cons in CONSTRAINED:  # -c: the model filters whole structures, the kernels apply the constraint per cell
+                dg, dist, count, mfe, db, _ = py_model.ensemble(pset, seq, T, cons=cons)
+                o = gpu_engine.fold_constrained([seq], [cons])
+                assert abs(float(o["dG"][0]) - dg) < 1e-9 * max(1.0, abs(dg)) and abs(float(o["mean_bp_dist"][0]) - dist) < 1e-9, (seq, cons, T)
+                assert int(o["mfe"][0]) == mfe, (seq, cons, T)
     finally:
         gpu_engine.load_params(base)
 

@@ -110,5 +110,43 @@ def test_kernel_code_against_the_independent_python_model(pset):
                 assert abs(float(o["dG"][0]) - dg) < 1e-9 * max(1.0, abs(dg)), (seq, T, o["dG"][0], dg)
                 assert abs(float(o["mean_bp_dist"][0]) - dist) < 1e-9, (seq, T)
                 assert int(eng.mfe_batch([seq])[0]) == mfe, (seq, T)
+            # and the constrained folds of the same code (sf_fold_constrained: the constraint at the pair-type seam of the kernels)
+            for seq, cons in CONSTRAINED:
+                dg, dist, count, mfe, db, _ = py_model.ensemble(pset, seq, T, cons=cons)
+                o = eng.fold_constrained([seq], [cons])
+                assert abs(float(o["dG"][0]) - dg) < 1e-9 * max(1.0, abs(dg)) and abs(float(o["mean_bp_dist"][0]) - dist) < 1e-9, (seq, cons, T)
+                assert int(o["mfe"][0]) == mfe, (seq, cons, T)
     finally:
         eng.load_params(params.default_params())
+
+
+CONSTRAINED = [
+    ("GGGAAACCCAGGGAAACCC", "xx....<............"),   # G1, G2 unpaired; C7 may only pair downstream
+    ("GGGAAACCCAGGGAAACCC", "(.......).........."),   # G1-C9 pair with each other only, nothing crosses them
+    ("GGAGCAAAGCAGCAAAGCACC", ".(.................)."),
+    ("GGAGCAAAGCAGCAAAGCACC", "..x.>..|....<......>."),
+    ("GGCAAGCAAAGCAAGCC", ">......x......<.."),
+    ("GACUUCGGUCAGGACUUUUGUCC", ".(......)....x........."),   # A2-U9 (a bracket pair of complementary bases)
+]
+
+
+@pytest.mark.parametrize("T", [37.0, 25.0])
+def test_hard_constraints_against_the_independent_python_model(oracle, pset, T):
+    """-c: the oracle applies a constraint per cell of its DP (pair-type seam: sf_oracle.c ptype()); the Python model filters whole
+    structures (x unpaired, < / > pair down- / upstream only, a bracket pair pairs with itself only and nothing crosses it).
+    Ensemble energy, ensemble diversity and MFE agree; every case really excludes structures."""
+    try:
+        oracle.set_params(pset.at_temperature(T))
+        for seq, cons in CONSTRAINED:
+            free = py_model.ensemble(pset, seq, T)
+            dg, dist, count, mfe, db, _ = py_model.ensemble(pset, seq, T, cons=cons)
+            assert 0 < count < free[2]
+            oracle.set_constraint(cons, None)
+            o = oracle.pf(seq)
+            assert abs(o["dG"] - dg) < 1e-9 * max(1.0, abs(dg)) and abs(o["mean_bp_dist"] - dist) < 1e-9, (seq, cons, T)
+            odb, oe = oracle.mfe(seq)
+            assert oe == mfe, (seq, cons, T, odb, db)
+            oracle.set_constraint(None, None)
+    finally:
+        oracle.set_constraint(None, None)
+        oracle.set_params(params.default_params())

@@ -141,8 +141,9 @@ class Model:
             e = 0.0
         return e + self._tau(typ)
 
-    def energy(self, seq, pt):
-        """pt: 1-based partner table (0 = unpaired), pt[0] unused.  dcal/mol."""
+    def energy(self, seq, pt, sc=None):
+        """pt: 1-based partner table (0 = unpaired), pt[0] unused.  dcal/mol.  sc: Deigan pseudo-energies per nucleotide (dcal,
+        0-based): a stack (i, j) on (i+1, j-1) pays those of its four nucleotides (ScanFold.py:522-544)."""
         n = len(seq)
         total = 0.0
         i = 1
@@ -170,6 +171,8 @@ class Model:
                 total += self.hairpin(seq, i, j)
             elif len(inner) == 1:
                 total += self.interior(seq, i, j, inner[0][0], inner[0][1])
+                if sc is not None and inner[0] == (i + 1, j - 1):
+                    total += sc[i - 1] + sc[i] + sc[j - 2] + sc[j - 1]
             else:
                 typ = PAIR[(seq[i - 1], seq[j - 1])]
                 self.seen.add("multiloop")
@@ -248,6 +251,18 @@ def admissible(pt, cons):
             if (i < a < j < b) or (a < i < b < j):
                 return False
     return True
+
+
+def mfe_with_shape(paramset, seq, temperature_c, sc):
+    """Minimum over every structure of the integer-table energy with the Deigan stack terms -> (dcal, dot-bracket)."""
+    m = Model(paramset, temperature_c, "mfe")
+    best, best_pt = None, None
+    for pt in structures(seq):
+        e = m.energy(seq, pt, sc)
+        if best is None or e < best:
+            best, best_pt = e, pt
+    n = len(seq)
+    return int(round(best)), "".join("." if best_pt[i] == 0 else ("(" if best_pt[i] > i else ")") for i in range(1, n + 1))
 
 
 def ensemble(paramset, seq, temperature_c, cons=None):

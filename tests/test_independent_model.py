@@ -150,3 +150,32 @@ def test_hard_constraints_against_the_independent_python_model(oracle, pset, T):
     finally:
         oracle.set_constraint(None, None)
         oracle.set_params(params.default_params())
+
+
+def test_deigan_stack_terms_against_the_independent_python_model(oracle, pset):
+    """SHAPE (Deigan): per-nucleotide pseudo-energies charged to stacks (fc.sc_add_SHAPE_deigan, ScanFold.py:522-544) — MFE of
+    the oracle and of the emulated kernel code == the minimum over all structures in the Python model; the terms change results."""
+    import os
+    from scanfold_amd import _lib
+    rng = np.random.default_rng(8)
+    emul = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emul", "libscanfold_emul.so")
+    eng = _lib.Engine(0, lib_path=emul) if os.path.exists(emul) else None
+    changed = 0
+    try:
+        oracle.set_params(pset.at_temperature(37.0))
+        for seq in SEQS[5:]:
+            sc = rng.integers(-120, 160, len(seq)).astype(np.int32)
+            want, _ = py_model.mfe_with_shape(pset, seq, 37.0, [int(x) for x in sc])
+            oracle.set_constraint(None, sc)
+            assert oracle.mfe(seq)[1] == want, seq
+            oracle.set_constraint(None, None)
+            changed += want != oracle.mfe(seq)[1]
+            if eng is not None:
+                eng.load_params(pset)
+                assert int(eng.fold_constrained([seq], None, sc.reshape(1, -1), pf=False)["mfe"][0]) == want, seq
+        assert changed >= 3
+    finally:
+        oracle.set_constraint(None, None)
+        oracle.set_params(params.default_params())
+        if eng is not None:
+            eng.load_params(params.default_params())

@@ -219,8 +219,8 @@ static inline void sf_fast_build_rows(int W, SfFastRows &R) {
   for (int sl = 0; sl < SF_FAST_NR; sl++)
     for (int u = 0; u < 32; u++) {
       const int row = ((sl - u) % SF_FAST_NR + SF_FAST_NR) % SF_FAST_NR;
-      ((u & 1) ? R.ci_odd : R.ci_even)[sl][u >> 1] = row * (W - 4) * 2;
-      ((u & 1) ? R.bn_odd : R.bn_even)[sl][u >> 1] = row * (W - 4) * 4;
+      if (u & 1) { R.ci_odd[sl][u >> 1] = row * (W - 4) * 2; R.bn_odd[sl][u >> 1] = row * (W - 4) * 4; }
+      else { R.ci_even[sl][u >> 1] = row * (W - 4) * 2; R.bn_even[sl][u >> 1] = row * (W - 4) * 4; }
     }
 }
 

@@ -86,6 +86,7 @@
 // loop sizes per batch of reads in the bulge / 1xn minima (narrow / wide kernel; measured 2, 3, 4, 6: W=120 best at
 // 3 by 0.6 %, W=200 at 6 by 3.5 %)
 #define SF_HELP_NB_128 4
+#define SF_HELP_NB_128G 8  // the generic merged-helper instantiation (W < 118): spill-free since the round-4 pins, it takes the longer batches — +2.2 % at W = 64 / 77, +1.6 % at W = 31, +0.7-1.3 % at W = 100; W = 120 and the generic W = 118 .. 128 kernel stay at 4 (59.0 against 59.8 ms; W = 128 -1.2 % with 8)
 #define SF_HELP_NB_256 6
 #define SF_INF16 30000
 #define SF_FAST_THRESH 10000
@@ -689,7 +690,8 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
         // (re-measured after the spill pins freed the generic narrow kernels' registers: still 0.4-3 % slower there)
         constexpr bool STAGED = (WT == 120);
         uint32_t acc = sf_pk(32767, 32767), accb = acc;
-        constexpr int SF_HELP_NB = FOLD ? SF_HELP_NB_256 : SF_HELP_NB_128;
+        // (WT == 0 && !TBLK: the merged-helper instantiation of the generic narrow kernel, W < 118)
+        constexpr int SF_HELP_NB = FOLD ? SF_HELP_NB_256 : ((WT == 0 && !TBLK) ? SF_HELP_NB_128G : SF_HELP_NB_128);
 #pragma unroll
         for (int ub = 2; ub <= 30; ub += SF_HELP_NB) {
           if (CH && ub > um) continue;

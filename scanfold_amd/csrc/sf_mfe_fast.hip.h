@@ -467,14 +467,10 @@ struct SfPub {
 // size tests above it (a scalar compare + branch each, ~110 of them) disappear from the first four steps of a fold, which
 // cost as much as full steps before (profiles/r03/mfe_step_profile.txt).
 // TBLK: the rolling rows' offsets come from the SfFastRows table (scalar loads) instead of the ring arithmetic — the kernel
-// decides per instantiation (measured: +4 % at W = 120 / 200, +3 % at W = 128; the merged-helper and the generic wide
-// instantiations, which already spill, lose 1-2 % and keep the arithmetic)
-// MGH: the call is the merged helper's (a lane's cell may lie on the step's odd diagonal: its rows are the even diagonal's plus one,
-// X.BN shifted by a row) — it must not reach a row through "the row after the next size's row": that is row + 2 for such a lane,
-// and only ONE mirror row follows the ring.  (Until round 4 it did: for slot2 == u, u even, the odd diagonal's lanes read "row 35",
-// i.e. the cell lists / parameter tables behind the mirror row.  The results stayed exact in every test because that garbage either
-// lost the minimum or tripped the int16-overflow fallback — found when the lists were moved in an experiment, profiles/r04.)
-template <bool G, int WT, int SEC, bool CH = false, bool FOLD = false, int UCAP = SFD_MAXLOOP, bool TBLK = true, bool MGH = false>
+// decides per instantiation (measured: +4 % at W = 120 / 200, +3 % at W = 128; the merged-helper instantiation lost 1-2 % while it
+// spilled and gains 1-3 % since the round-4 pins — W = 64 +1.0, 77 +1.8, 100 +1.4, 117 +3.1 %; the generic wide instantiation, which
+// still spills, keeps the arithmetic)
+template <bool G, int WT, int SEC, bool CH = false, bool FOLD = false, int UCAP = SFD_MAXLOOP, int TBLK = 1, bool MGH = false>
 __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, const int i, const bool valid,
                                              const int slot2, const int slotd, uint32_t (&HP)[14], int &ovf,
                                              const bool final_fml, const int fnb, int &fpart, int &dec, int &eh, int &e0,
@@ -546,7 +542,7 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
 // build spills registers — see SF_UNI — so the scalar unit keeps computing them)
 #define ROW(u) ((slot2 - (u) < 0 ? slot2 - (u) + SF_FAST_NR : slot2 - (u)) * RW)
   // TBL (the all-sizes code): the rows' byte offsets come from SfFastRows — scalar loads of consecutive entries
-  constexpr bool TBL = !G && TBLK && SF_FAST_ROWTAB;
+  constexpr bool TBL = !G && (TBLK != 0) && SF_FAST_ROWTAB;
   const SfFastRows *const Rc = TBL ? sf_const_base(X.R) : X.R;  // (the base is pinned by a volatile asm: only where it is used)
   const int32_t *const rci_o = Rc->ci_odd[slot2], *const rci_e = Rc->ci_even[slot2];
   const int32_t *const rbn_o = Rc->bn_odd[slot2], *const rbn_e = Rc->bn_even[slot2];
@@ -690,8 +686,8 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
         // (re-measured after the spill pins freed the generic narrow kernels' registers: still 0.4-3 % slower there)
         constexpr bool STAGED = (WT == 120);
         uint32_t acc = sf_pk(32767, 32767), accb = acc;
-        // (WT == 0 && !TBLK: the merged-helper instantiation of the generic narrow kernel, W < 118)
-        constexpr int SF_HELP_NB = FOLD ? SF_HELP_NB_256 : ((WT == 0 && !TBLK) ? SF_HELP_NB_128G : SF_HELP_NB_128);
+        // (TBLK == 2: the merged-helper instantiation of the generic narrow kernel, W < 118)
+        constexpr int SF_HELP_NB = FOLD ? SF_HELP_NB_256 : (TBLK == 2 ? SF_HELP_NB_128G : SF_HELP_NB_128);
 #pragma unroll
         for (int ub = 2; ub <= 30; ub += SF_HELP_NB) {
           if (CH && ub > um) continue;
@@ -1437,7 +1433,9 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
   X.S = S;
   X.D = D; X.F = F; X.R = Rows; X.W = W; X.fold = FOLD; X.maxd = D->max_pair_dist;
   constexpr bool MERGE = MG && SF_HELP_MERGE && (NG == 128);
-  constexpr bool TBLK = WT > 0 || (NG == 128 && !MG);  // rolling-row offsets from SfFastRows (see sf_fast_cell)
+  // rolling-row offsets from SfFastRows (see sf_fast_cell): 1 = yes, 2 = yes + the long read batches of the generic merged-helper
+  // instantiation, 0 = no (the generic wide kernel)
+  constexpr int TBLK = WT > 0 ? 1 : (NG == 128 ? (MG ? 2 : 1) : 0);
   X.bn_dup = (NG == 128);
   // (W >= SF_HELP_MERGE_MAXW with the merged helper — the W = 120 instantiation: its two 128-byte cell lists do not fit the 40 960 B
   // of four workgroups per CU, so they take the place of the LDS copy of the size tables, which only the first four steps of a fold

@@ -140,46 +140,75 @@ def cpu_quota():
     return None
 
 
-def cpu_baseline(seq, W, step, r, kind, seed, budget_s=15.0):
+def cpu_baseline(seq, W, step, r, kind, seed, budget_s=12.0):
     """The CPU engine (oracle/sf_cpu_twin.c when built, else the checker oracle/sf_oracle.c) on a bounded sample of
     the same workload: per window 1 MFE + traceback, 1 partition function and r+1 MFE folds, one OpenMP thread per
-    window, threads = physical cores.  Baseline only — never the product, never ViennaRNA (absent)."""
+    window, threads = physical cores (capped by the container's CPU quota).  TWO builds of the same sources are timed on
+    the same sample: the portable one (`-O3`, what travels with the repository) and one made NOW, on this host, the way a
+    user would build for it (`-O3 -march=native`, oracle.build_native); `value` is the FASTER of the two.
+    Baseline only — never the product, never ViennaRNA (absent)."""
     import numpy as np
     from oracle import oracle
     from scanfold_amd import params
     oracle.build()
-    oracle.set_params(params.default_params())
+    pset = params.default_params()
+    oracle.set_params(pset)
     threads, phys, socks = host_cores()
     quota = cpu_quota()
     cores = phys if quota is None else min(phys, quota)
     engine = "oracle/sf_oracle.c (the parity checker: O(n^4) outside pass, allocations per fold)"
-    scan_fn = oracle.scan_windows
-    if hasattr(oracle, "twin_available") and oracle.twin_available():
+    twin = hasattr(oracle, "twin_available") and oracle.twin_available()
+    if twin:
         engine = ("oracle/sf_cpu_twin.c (per-thread workspaces, pair-type matrix, dense interior loops with pre-added "
                   "mismatch view, vectorisable multiloop split, O(n^3) outside pass)")
-        scan_fn = oracle.twin_scan_windows
+    native, native_err = None, None
+    if twin:
+        try:
+            native = oracle.lib_native()
+            oracle.set_params(pset, L=native)
+        except Exception as e:  # no compiler on the box, or the build failed: the portable build stands alone
+            native, native_err = None, repr(e)
 
-    def run(n_win):
+    def run(n_win, L=None):
         rows = np.frombuffer(b"NACGU", dtype=np.uint8)[oracle.shuffle_windows(seq, W, step, 0, n_win, r, kind, seed)]
         t0 = time.perf_counter()
-        scan_fn(rows, n_win, r, nthreads=cores)
-        return time.perf_counter() - t0
+        if twin:
+            res = oracle.twin_scan_windows(rows, n_win, r, nthreads=cores, L=L)
+        else:
+            res = oracle.scan_windows(rows, n_win, r, nthreads=cores)
+        return time.perf_counter() - t0, res
     n0 = max(cores, 8)
-    t0 = run(n0)
+    t0, _ = run(n0)
     n = int(max(n0, min(20000, n0 * budget_s / max(t0, 1e-6))))
     n = (n // cores) * cores or n0
-    t = run(n)
+    t, res = run(n)
+    builds = [{"flags": oracle.BASE_FLAGS, "windows_per_s": n / t, "per_core_windows_per_s": n / t / cores, "wall_s": t,
+               "built": "in the build container, travels with the tree (oracle/Makefile CFLAGS)"}]
+    if native is not None:
+        tn, resn = run(n, L=native)
+        same = bool((res["energies"] == resn["energies"]).all() and res["structure"] == resn["structure"]
+                    and res["centroid"] == resn["centroid"])
+        builds.append({"flags": oracle.NATIVE_FLAGS, "windows_per_s": n / tn, "per_core_windows_per_s": n / tn / cores,
+                       "wall_s": tn, "built": "on this host just now (oracle.build_native; oracle/Makefile NATIVE_FLAGS)",
+                       "cpu": oracle._cpu_stamp().split(" | ")[0], "results_equal_the_portable_build": same,
+                       "speedup_over_portable": t / tn})
+    best = max(builds, key=lambda b: b["windows_per_s"])
     try:
         overhead = reference_python_overhead(seq, W, r, windows=4)
     except Exception as e:  # never let the side measurement break the bench line
         overhead = {"error": repr(e)}
-    return dict(value=n / t, unit="windows/s", cores=cores, kind="port", reference_python_overhead=overhead,
-                host={"hardware_threads": threads, "physical_cores": phys, "sockets": socks, "cgroup_cpu_quota": quota},
-                sample="first %d windows of the workload, one OpenMP thread per window on %d threads (%s; the host has "
-                       "%d physical cores in %d socket(s), %d hardware threads); each window: 1 MFE + traceback, 1 "
-                       "partition function, %d MFE folds; %.1f s wall; engine: %s — not ViennaRNA (absent)"
-                       % (n, cores, "the container's CPU quota" if quota is not None and quota < phys else
-                          "one per physical core", phys, socks, threads, r + 1, t, engine))
+    out = dict(value=best["windows_per_s"], unit="windows/s", cores=cores, kind="port", flags=best["flags"],
+               per_core=best["per_core_windows_per_s"], builds=builds, reference_python_overhead=overhead,
+               host={"hardware_threads": threads, "physical_cores": phys, "sockets": socks, "cgroup_cpu_quota": quota},
+               sample="first %d windows of the workload, one OpenMP thread per window on %d threads (%s; the host has "
+                      "%d physical cores in %d socket(s), %d hardware threads); each window: 1 MFE + traceback, 1 "
+                      "partition function, %d MFE folds; %.1f s wall per build (%d build(s) timed on the same sample, `value` = the "
+                      "faster: %s); engine: %s — not ViennaRNA (absent)"
+                      % (n, cores, "the container's CPU quota" if quota is not None and quota < phys else
+                         "one per physical core", phys, socks, threads, r + 1, best["wall_s"], len(builds), best["flags"], engine))
+    if native_err:
+        out["native_build_error"] = native_err
+    return out
 
 
 def _noop(x):
@@ -294,6 +323,15 @@ def reference_python_overhead(seq, W, r, windows=6):
             "windows_per_s_if_folds_were_free": 1.0 / (t_shuffle + t_pool)}
 
 
+def verify_indices(n_loc, n_check):
+    """The windows verify_sample checks: n_check of n_loc, evenly spread, first and last included."""
+    import numpy as np
+    n_check = min(n_check, n_loc)
+    if n_check <= 0:
+        return np.zeros(0, dtype=np.int64)
+    return np.unique(np.linspace(0, n_loc - 1, n_check).astype(np.int64))
+
+
 def verify_sample(seq, W, step, r, kind, seed, lo, n_loc, en, db, cen, div, n_check=64, paramset=None):
     """Compare n_check windows of the LAST timed step (device tensors of rank 0's shard) with the oracle: every one
     of the r+1 energies on the oracle's own shuffles, structure, centroid, ensemble diversity.  Returns
@@ -303,10 +341,9 @@ def verify_sample(seq, W, step, r, kind, seed, lo, n_loc, en, db, cen, div, n_ch
     from scanfold_amd import params
     oracle.build()
     oracle.set_params(paramset if paramset is not None else params.default_params())
-    n_check = min(n_check, n_loc)
-    if n_check <= 0:
+    idx = verify_indices(n_loc, n_check)
+    if len(idx) == 0:
         return 0, 0
-    idx = np.unique(np.linspace(0, n_loc - 1, n_check).astype(np.int64))
     e_dev = en[idx].cpu().numpy()
     db_dev = db[idx].cpu().numpy()
     cen_dev = cen[idx].cpu().numpy()
@@ -355,20 +392,36 @@ def main():
         print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
         return 2
     n_dev = torch.cuda.device_count()  # does not initialise the GPU
-    if n_dev < world or local_rank >= n_dev:
+    # SCANFOLD_DIST_BACKEND=gloo + SCANFOLD_DEVICE=k: several ranks on ONE GPU (RCCL refuses that), the collective staged
+    # through the host — how the -m gpu suite runs this file with world > 1 on a one-GPU box (tests/test_gpu_paths.py)
+    backend = os.environ.get("SCANFOLD_DIST_BACKEND", "nccl")
+    if backend not in ("nccl", "gloo"):
+        print("bench.py: SCANFOLD_DIST_BACKEND must be nccl or gloo", file=sys.stderr)
+        return 2
+    dev_index = local_rank
+    if backend == "gloo" and os.environ.get("SCANFOLD_DEVICE", "") != "":
+        dev_index = int(os.environ["SCANFOLD_DEVICE"])
+    elif n_dev < world:
         print("bench.py rank %d: --gpus %d needs %d GPUs, %d GPU(s) visible" % (rank, args.gpus, world, n_dev),
               file=sys.stderr)
         return EXIT_NEED_GPUS
+    if dev_index >= n_dev:
+        print("bench.py rank %d: device %d of %d GPU(s) visible" % (rank, dev_index, n_dev), file=sys.stderr)
+        return EXIT_NEED_GPUS
     from scanfold_amd import _lib, dist as sdist
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     # SCANFOLD_BENCH_FORCE_DIST=1 (under torch.distributed.run --nproc-per-node 1): take the RCCL path with a single
     # rank — process group, record packing and a one-rank all_gather_into_tensor — on a one-GPU box
     force_dist = os.environ.get("SCANFOLD_BENCH_FORCE_DIST") == "1"
     use_dist = world > 1 or force_dist
     if use_dist:
-        dist.init_process_group("nccl", device_id=dev)
-    eng = _lib.Engine(device=local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")  # where the small collectives' tensors live
+    eng = _lib.Engine(device=dev_index)
 
     wl = dict(WORKLOADS[args.config])
     if args.shuffle:
@@ -418,8 +471,13 @@ def main():
         gathered = step_fn()
     sync()
     elapsed = time.perf_counter() - t0
+    rank_elapsed = [elapsed]
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        mine_t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
+        every = torch.zeros(world, dtype=torch.float64, device=coll_dev)
+        dist.all_gather_into_tensor(every, mine_t)
+        rank_elapsed = [float(x) for x in every.cpu()]
+        t = mine_t.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kern_ms, launches, folds = eng.prof_get()
@@ -486,12 +544,17 @@ def main():
                         and (merged["ens_dG"][mine] == dG[:n_loc].cpu().numpy()).all())
             gather_check = {"backend": dist.get_backend(), "ranks": world, "windows": n_win,
                             "bytes_per_rank": int(gathered.shape[0] // world * gathered.shape[1]),
-                            "rank0_shard_equals_its_device_tensors": same}
+                            "rank0_shard_equals_its_device_tensors": same,
+                            "shard_ranges": [list(sdist.shard_range(n_win, k, world)) for k in range(world)],
+                            "rank_elapsed_s": rank_elapsed, "elapsed_is_max_over_ranks": elapsed == max(rank_elapsed)}
             # verify on the gathered records of all shards: torch tensors on the host in the layout verify_sample reads
             v_en, v_db = torch.from_numpy(merged["energies"]), torch.from_numpy(merged["structure"])
             v_cen, v_div = torch.from_numpy(merged["centroid"]), torch.from_numpy(merged["ens_div"])
             checked, bad = verify_sample(seq, W, step, r, kind, wl["shuffle_seed"], 0, n_win, v_en, v_db, v_cen, v_div,
                                          wl["verify"])
+            picked = verify_indices(n_win, wl["verify"])
+            gather_check["verified_windows_per_shard"] = [int(((picked >= a) & (picked < b)).sum())
+                                                          for a, b in gather_check["shard_ranges"]]
             if not same:
                 bad += 1
         else:

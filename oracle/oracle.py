@@ -19,38 +19,93 @@ def build(force=False):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
 
 
+BASE_FLAGS = "-O3 -std=c11 -fPIC -fopenmp"  # oracle/Makefile CFLAGS (warnings aside)
+NATIVE_FLAGS = "-O3 -march=native -std=c11 -fPIC -fopenmp"  # oracle/Makefile NATIVE_FLAGS (warnings aside)
+_NATIVE_DIR = os.path.join(_HERE, "_native")
+_NATIVE_LIB = os.path.join(_NATIVE_DIR, "libsf_oracle_native.so")
+_native = None
+
+
+def _cpu_stamp():
+    """What `-march=native` depends on: the host's CPU model and ISA flags, and the compiler."""
+    model = flags = ""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name") and not model:
+                model = ln.split(":", 1)[1].strip()
+            elif ln.startswith("flags") and not flags:
+                flags = ln.split(":", 1)[1].strip()
+            if model and flags:
+                break
+    except OSError:
+        pass
+    cc = subprocess.run(["gcc", "--version"], capture_output=True, text=True).stdout.splitlines()[:1]
+    import hashlib
+    return "%s | %s | %s | %s" % (model, hashlib.sha1(flags.encode()).hexdigest()[:12], cc[0] if cc else "gcc ?", NATIVE_FLAGS)
+
+
+def build_native():
+    """The same sources a second time, `-O3 -march=native`, ON THE MACHINE THAT WILL RUN IT (the object must not
+    travel between hosts: oracle/_native/ is git- and gpurun-ignored and carries a stamp of the CPU it was built for).
+    bench.py's cpu_baseline times this build beside the portable one.  -> path of the library."""
+    stamp_path = os.path.join(_NATIVE_DIR, "built_for.txt")
+    stamp = _cpu_stamp()
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith(".c")]
+    fresh = (os.path.exists(_NATIVE_LIB) and os.path.exists(stamp_path) and open(stamp_path).read() == stamp
+             and os.path.getmtime(_NATIVE_LIB) >= max(os.path.getmtime(f) for f in srcs))
+    if not fresh:
+        if os.path.exists(_NATIVE_LIB):
+            os.remove(_NATIVE_LIB)
+        subprocess.check_call(["make", "-C", _HERE, "-s", "native"])
+        with open(stamp_path, "w") as f:
+            f.write(stamp)
+    return _NATIVE_LIB
+
+
+def lib_native():
+    """The -march=native build as a SECOND library instance (its own parameter tables: call set_params(p, L=lib_native()))."""
+    global _native
+    if _native is None:
+        _native = _bind(ctypes.CDLL(build_native()))
+    return _native
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(_LIB):
             build()
-        L = ctypes.CDLL(_LIB)
-        L.sfo_set_params.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
-        L.sfo_set_params_exact.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_char_p]
-        L.sfo_mfe.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_char_p]
-        L.sfo_mfe_batch.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
-        L.sfo_eval.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
-        L.sfo_brute.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
-                                ctypes.POINTER(ctypes.c_double), ctypes.c_void_p,
-                                ctypes.POINTER(ctypes.c_longlong)]
-        L.sfo_pf.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.c_void_p,
-                             ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
-        L.sfo_scan_windows.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
-                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
-        L.sfo_twin_scan_windows.argtypes = L.sfo_scan_windows.argtypes
-        L.sfo_twin_mfe_batch.argtypes = L.sfo_mfe_batch.argtypes
-        L.sfo_set_constraint.argtypes = [ctypes.c_char_p, ctypes.c_void_p]
-        L.sfo_shuffle_windows.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-                                          ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.c_void_p]
-        _lib = L
+        _lib = _bind(ctypes.CDLL(_LIB))
     return _lib
 
 
-def set_params(paramset):
+def _bind(L):
+    L.sfo_set_params.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    L.sfo_set_params_exact.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_char_p]
+    L.sfo_mfe.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_char_p]
+    L.sfo_mfe_batch.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    L.sfo_eval.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+    L.sfo_brute.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
+                            ctypes.POINTER(ctypes.c_double), ctypes.c_void_p,
+                            ctypes.POINTER(ctypes.c_longlong)]
+    L.sfo_pf.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.c_void_p,
+                         ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+    L.sfo_scan_windows.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    L.sfo_twin_scan_windows.argtypes = L.sfo_scan_windows.argtypes
+    L.sfo_twin_mfe_batch.argtypes = L.sfo_mfe_batch.argtypes
+    L.sfo_set_constraint.argtypes = [ctypes.c_char_p, ctypes.c_void_p]
+    L.sfo_shuffle_windows.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                      ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.c_void_p]
+    return L
+
+
+def set_params(paramset, L=None):
+    L = L or lib()
     blob = paramset.blob()
-    assert len(blob) == lib().sfo_params_size(), (len(blob), lib().sfo_params_size())
+    assert len(blob) == L.sfo_params_size(), (len(blob), L.sfo_params_size())
     b37, bdh = paramset.rescale_blobs()
-    rc = lib().sfo_set_params_exact(blob, len(blob), b37, bdh)
+    rc = L.sfo_set_params_exact(blob, len(blob), b37, bdh)
     if rc:
         raise RuntimeError("sfo_set_params rc=%d" % rc)
 
@@ -165,16 +220,17 @@ def twin_available():
     return hasattr(lib(), "sfo_twin_scan_windows")
 
 
-def twin_scan_windows(rows, n_win, r, nthreads=0):
-    """sf_cpu_twin.c: the same job as scan_windows on the fast CPU engine (bench.py's cpu_baseline)."""
+def twin_scan_windows(rows, n_win, r, nthreads=0, L=None):
+    """sf_cpu_twin.c: the same job as scan_windows on the fast CPU engine (bench.py's cpu_baseline); L = lib_native() runs
+    the -march=native build."""
     arr = np.ascontiguousarray(rows, dtype=np.uint8)
     W = arr.shape[1]
     en = np.empty((n_win, r + 1), dtype=np.int32)
     db = np.zeros((n_win, W + 1), dtype=np.uint8)
     cen = np.zeros((n_win, W + 1), dtype=np.uint8)
     ed = np.zeros(n_win)
-    rc = lib().sfo_twin_scan_windows(arr.ctypes.data_as(ctypes.c_char_p), n_win, r, W, en.ctypes.data, db.ctypes.data,
-                                     cen.ctypes.data, ed.ctypes.data, nthreads)
+    rc = (L or lib()).sfo_twin_scan_windows(arr.ctypes.data_as(ctypes.c_char_p), n_win, r, W, en.ctypes.data, db.ctypes.data,
+                                            cen.ctypes.data, ed.ctypes.data, nthreads)
     if rc:
         raise RuntimeError("sfo_twin_scan_windows rc=%d" % rc)
     return dict(energies=en, structure=[bytes(x[:W]).decode() for x in db],

@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <map>
 #include <string>
 #include <vector>
 
@@ -57,9 +58,10 @@ struct Ctx {
   uint64_t loads = 0;
   int cur = 0;
   double temperature = 37.0;
-  DevBuf full_scratch, pf_scratch, pf_share, fast_scratch, fast_rows, seqs, energies, db, cen, dbl, status, transcript, ovf, cons, sc;
-  int fast_rows_W = 0;            // the width g.fast_rows holds the rolling-row offsets for (0: none)
-  SfFastRows fast_rows_host;
+  DevBuf full_scratch, pf_scratch, pf_share, fast_scratch, seqs, energies, db, cen, dbl, status, transcript, ovf, cons, sc;
+  // the rolling-row offsets (SfFastRows, 8.7 kB) of every width that has been launched: one device table per width, written
+  // once and never again, so launches of different widths on different caller streams (sf_mfe_device) cannot see each other's
+  std::map<int, SfFastRows *> fast_rows;
   DevBuf tab_in, tab_partner, tab_counts, tab_out;  // sf_tabulate_pairs
   int64_t tab_groups = -1;
   std::string last_hip_error;
@@ -344,7 +346,14 @@ struct ProfPair {
 static int mfe_poison() {
   const char *e = getenv("SCANFOLD_MFE_POISON");
   const int v = e ? atoi(e) : 0;
-  return v >= 1 && v <= 5 ? v : 0;
+  if (v < 1 || v > 5) return 0;
+  static bool said = false;
+  if (!said) {  // a test hook in the product library: never silent
+    fprintf(stderr, "scanfold_hip: SCANFOLD_MFE_POISON=%d — TEST MODE: the MFE kernel refills its LDS slack with an adversarial "
+                    "pattern before every fold (slower; results must not change). Unset it for production runs.\n", v);
+    said = true;
+  }
+  return v;
 }
 
 // d_cons / d_sc: every fold has its own hard constraint / Deigan pseudo-energies (row k of each; trace_stride 1): the
@@ -371,23 +380,32 @@ int launch_mfe(const uint8_t *d_seqs, int n, int W, int32_t *d_out, hipStream_t 
     HIPCHK(hipMemsetAsync(d_cnt, 0, 2 * sizeof(int), st));
     rc = ensure(g.fast_scratch, scratch_bytes);
     if (rc) return rc;
-    // the rolling rows' offsets for this width (SfFastRows; stream-ordered behind the launches that read the previous table)
-    rc = ensure(g.fast_rows, sizeof(SfFastRows));
-    if (rc) return rc;
-    if (g.fast_rows_W != W) {
-      sf_fast_build_rows(W, g.fast_rows_host);
-      HIPCHK(hipMemcpyAsync(g.fast_rows.p, &g.fast_rows_host, sizeof(SfFastRows), hipMemcpyHostToDevice, st));
-      HIPCHK(hipStreamSynchronize(st));  // (the host copy is reused by the next width)
-      g.fast_rows_W = W;
+    // the rolling rows' offsets for this width (SfFastRows): built on first use, immutable afterwards
+    const SfFastRows *d_rows = nullptr;
+    {
+      auto it = g.fast_rows.find(W);
+      if (it == g.fast_rows.end()) {
+        static SfFastRows host_rows;
+        SfFastRows *d = nullptr;
+        sf_fast_build_rows(W, host_rows);
+        HIPCHK(hipMalloc((void **)&d, sizeof(SfFastRows)));
+        if (hipMemcpy(d, &host_rows, sizeof(SfFastRows), hipMemcpyHostToDevice) != hipSuccess) {  // synchronous: host_rows is reused
+          hipFree(d);
+          g.last_hip_error = "hipMemcpy of the rolling-row offset table failed";
+          return SF_ERR_HIP;
+        }
+        it = g.fast_rows.emplace(W, d).first;
+      }
+      d_rows = it->second;
     }
     if ((rc = prof.begin(st))) return rc;
     if (hc)
       sf_fast_launch_hc(grid, threads, lds, st, d_seqs, n, W, (const SfDevParams *)g.dP, (const SfFastParams *)g.dF,
-                        (const SfFastRows *)g.fast_rows.p, (int16_t *)g.fast_scratch.p, d_out, d_cnt, d_list, trace_stride, d_db, (int *)g.status.p, d_work,
+                        d_rows, (int16_t *)g.fast_scratch.p, d_out, d_cnt, d_list, trace_stride, d_db, (int *)g.status.p, d_work,
                         d_cons, d_sc);
     else
       sf_fast_launch(mfe_poison(), grid, threads, lds, st, d_seqs, n, W, (const SfDevParams *)g.dP, (const SfFastParams *)g.dF,
-                     (const SfFastRows *)g.fast_rows.p, (int16_t *)g.fast_scratch.p, d_out, d_cnt, d_list, trace_stride, d_db, (int *)g.status.p,
+                     d_rows, (int16_t *)g.fast_scratch.p, d_out, d_cnt, d_list, trace_stride, d_db, (int *)g.status.p,
                      d_work, (const char *)nullptr, (const int32_t *)nullptr);
     HIPCHK(hipGetLastError());
     if ((rc = prof.end(st))) return rc;
@@ -479,7 +497,7 @@ int sf_init(int device_ordinal) {
 int sf_shutdown(void) {
   if (!g.init) return SF_OK;
   hipDeviceSynchronize();
-  DevBuf *bufs[] = {&g.full_scratch, &g.pf_scratch, &g.pf_share, &g.fast_scratch, &g.fast_rows, &g.seqs, &g.energies, &g.db, &g.cen,
+  DevBuf *bufs[] = {&g.full_scratch, &g.pf_scratch, &g.pf_share, &g.fast_scratch, &g.seqs, &g.energies, &g.db, &g.cen,
                     &g.dbl, &g.status, &g.transcript, &g.ovf, &g.cons, &g.sc, &g.tab_in, &g.tab_partner, &g.tab_counts,
                     &g.tab_out};
   for (DevBuf *b : bufs) {
@@ -499,7 +517,8 @@ int sf_shutdown(void) {
   if (g.stream) hipStreamDestroy(g.stream);
   g.stream = nullptr;
   g.init = false;
-  g.fast_rows_W = 0;
+  for (auto &kv : g.fast_rows) hipFree(kv.second);
+  g.fast_rows.clear();
   g.have_params = false;
   return SF_OK;
 }

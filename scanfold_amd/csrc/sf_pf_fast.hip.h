@@ -28,6 +28,19 @@ struct SfPfTabs {
   double *QB, *QBI, *QB1N, *QBB, *QM, *QM1, *OB, *OBI, *OB1N, *OBB, *OBW, *A0, *A1;
 };
 
+// Parts a cell's O(d) multiloop sums are split into on diagonal d (n = W - d cells, NT threads): NT / n, capped — the cell's
+// owner adds the partial sums one after the other from LDS, so on the last diagonals (n -> 1) an uncapped NT / n would trade a
+// chain of d global loads for a chain of 256 LDS reads in ONE thread while the workgroup waits at the barrier.  With the cap a
+// part walks <= ceil(d / 16) terms and the owner adds <= 16.  (The summation order differs from the LDS kernel's and the
+// oracle's at ~1e-13; a pair probability within that of 0.5 could fall on either side of the centroid's threshold — DESIGN.md.)
+#ifndef SF_PFF_MAXPARTS
+#define SF_PFF_MAXPARTS 16
+#endif
+__host__ __device__ static inline int sf_pff_parts(int nt, int n) {
+  const int k = nt / n;
+  return k < SF_PFF_MAXPARTS ? k : SF_PFF_MAXPARTS;
+}
+
 // HC: fold k has its own hard constraint, W characters at cons_rows + k * row_stride * W (fc.hc_add_from_db before fc.pf(),
 // ScanFold-Scan.py:405-412).  As in the LDS kernels the constraint acts where a cell's OWN pair type is made (inside, the
 // two exterior sums, outside): a forbidden pair has qb = 0 and drops out of every sum that reads it; the types of enclosed /
@@ -108,7 +121,7 @@ __global__ __launch_bounds__(NT, 2) void sf_pf_fast_kernel(const uint8_t *__rest
     // thread (2 / 4 / 8) no longer matter.
     auto inside_sums = [&](const int d) {
       const SfDevParams *const Dc = sf_const_base(D);
-      const int n = W - d, kk = NT / n;
+      const int n = W - d, kk = sf_pff_parts(NT, n);
       const int p = tid / n, c = tid - p * n;
       if (p < kk) {
         const int i = c + 1, j = i + d;
@@ -190,7 +203,7 @@ __global__ __launch_bounds__(NT, 2) void sf_pf_fast_kernel(const uint8_t *__rest
           }
           double ml = 0.0;
           {
-            const int n = W - d, kk = NT / n;
+            const int n = W - d, kk = sf_pff_parts(NT, n);
             for (int q = 0; q < kk; q++) ml += ps0[q * n + i - 1];
           }
           z += ml * Xc->MLclosing * sfx_mlstem(Xc, sfd_rtype(type), sj1, si1);
@@ -208,7 +221,7 @@ __global__ __launch_bounds__(NT, 2) void sf_pf_fast_kernel(const uint8_t *__rest
           PT(T.QM1, d, i) = m1;
           double m = m1;
           {
-            const int n = W - d, kk = NT / n;
+            const int n = W - d, kk = sf_pff_parts(NT, n);
             for (int q = 0; q < kk; q++) m += ps1[q * n + i - 1];
           }
           PT(T.QM, d, i) = m;
@@ -265,7 +278,7 @@ __global__ __launch_bounds__(NT, 2) void sf_pf_fast_kernel(const uint8_t *__rest
     // read diagonals > d only, all complete: split over the idle threads like the inside sums)
     auto outside_sums = [&](const int d) {
       const SfDevParams *const Dc = sf_const_base(D);
-      const int n = W - d, kk = NT / n;
+      const int n = W - d, kk = sf_pff_parts(NT, n);
       const int p = tid / n, c = tid - p * n;
       if (p < kk) {
         const int i = c + 1, j = i + d;
@@ -328,7 +341,7 @@ __global__ __launch_bounds__(NT, 2) void sf_pf_fast_kernel(const uint8_t *__rest
         if (i > 1) {
           a0 = PT(T.A0, d + 1, i - 1) * Xc->MLbase + PT(T.OBW, d + 1, i - 1);
           {
-            const int n = W - d, kk = NT / n;
+            const int n = W - d, kk = sf_pff_parts(NT, n);
             for (int q = 0; q < kk; q++) a1 += ps0[q * n + i - 1];
           }
         }
@@ -399,7 +412,7 @@ __global__ __launch_bounds__(NT, 2) void sf_pf_fast_kernel(const uint8_t *__rest
               // closers (k, l) with l = i + dd <= W; dd = d+1 has an empty right part, the spans >= d + 2 come from outside_sums
               const int ddmax = sfd_min(W - 1, W - i);
               if (d + 1 <= ddmax) mlsum += PT(T.A1, d + 1, i) * mlb[0];
-              const int n = W - d, kk = NT / n;
+              const int n = W - d, kk = sf_pff_parts(NT, n);
               for (int q = 0; q < kk; q++) mlsum += ps1[q * n + i - 1];
             }
             o += mlsum * sfx_mlstem(Xc, type, sp1, sq1);

@@ -75,6 +75,10 @@ def gather_records(local_rec, world, force=False):
     import torch.distributed as dist
     if world == 1 and not force:
         return local_rec
+    if dist.get_backend() == "gloo" and local_rec.is_cuda:
+        # gloo (the tests' stand-in for RCCL when several ranks share ONE GPU): the shard is staged through the host for
+        # the collective only, exactly as gather_rows does; packing stays on the device
+        local_rec = local_rec.cpu()
     out = torch.empty((world * local_rec.shape[0], local_rec.shape[1]), dtype=torch.uint8, device=local_rec.device)
     dist.all_gather_into_tensor(out, local_rec.contiguous())
     return out
@@ -130,10 +134,12 @@ def any_rank_failed(failed_here, world, device=None):
     return bool(int(flag.item()))
 
 
-def gather_rows(rows, n_items, rank, world, W, device=None, want=True):
+def gather_rows(rows, n_items, rank, world, W, device=None, want=True, prepacked=None):
     """Every rank hands in the TSV rows of ITS window range (formatted where they were computed); ONE all-gather of
     fixed-size row slots returns all n_items rows in window order (want=False: None — a rank that does not write).
-    `device`: where the collective's tensors live (the rank's GPU under nccl/RCCL, None = host under gloo)."""
+    `device`: where the collective's tensors live (the rank's GPU under nccl/RCCL, None = host under gloo).
+    `prepacked`: pack_rows(rows, shard_size(n_items, world), row_slot_width(W)) if the caller has made it already (the sharded
+    scan packs before its status all-reduce, so that a row that does not fit fails on every rank, not inside the collective)."""
     import torch
     import torch.distributed as dist
     lo, hi = shard_range(n_items, rank, world)
@@ -142,7 +148,9 @@ def gather_rows(rows, n_items, rank, world, W, device=None, want=True):
     if world == 1:
         return list(rows)
     per, width = shard_size(n_items, world), row_slot_width(W)
-    local = torch.from_numpy(pack_rows(rows, per, width))
+    if prepacked is not None and prepacked.shape != (per, width):
+        raise ValueError("prepacked rows have shape %r, the gather needs %r" % (prepacked.shape, (per, width)))
+    local = torch.from_numpy(prepacked if prepacked is not None else pack_rows(rows, per, width))
     if device is not None:
         local = local.to(device)
     out = torch.empty((world * per, width), dtype=torch.uint8, device=local.device)

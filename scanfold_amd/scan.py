@@ -142,6 +142,8 @@ def _chunk_bounds(lo, hi, chunk=None):
     explicit = chunk or os.environ.get("SCANFOLD_CHUNK_WINDOWS")
     if explicit:
         c = int(explicit)
+        if c < 1:
+            raise ValueError("windows per engine call (chunk / SCANFOLD_CHUNK_WINDOWS) must be >= 1, got %d" % c)
         return [(w0, min(c, hi - w0)) for w0 in range(lo, hi, c)]
     if n <= CHUNK_WINDOWS:
         return [(lo, n)] if n > 0 else []
@@ -355,10 +357,13 @@ def scan_record_sharded(seq, W, step, r, shuffle_type, temperature, eng, seed, r
     # A failure that only one rank sees (an unbalanced constraint in ITS windows, a row that does not fit its gather slot)
     # must not leave the others waiting in the collective: every rank reports how its shard went, one tiny all-reduce, and
     # either everybody gathers or everybody raises.
-    rows, err = None, None
+    rows, packed, err = None, None, None
     try:
         rows = scan_record(seq, W, step, r, shuffle_type, temperature, eng, seed=seed, windows=(lo, hi), **kw)
-        sdist.pack_rows(rows, len(rows), sdist.row_slot_width(W))  # (raises if a row is too long for its slot)
+        if len(rows) != hi - lo:
+            raise ValueError("rank %d formatted %d rows for the range [%d, %d)" % (rank, len(rows), lo, hi))
+        # packed ONCE, here (raises if a row is too long for its slot); gather_rows ships this array
+        packed = sdist.pack_rows(rows, sdist.shard_size(n_win, world), sdist.row_slot_width(W))
     except Exception as e:  # noqa: BLE001 — re-raised below, on every rank
         err = e
     failed = sdist.any_rank_failed(err is not None, world, device=device)
@@ -367,7 +372,7 @@ def scan_record_sharded(seq, W, step, r, shuffle_type, temperature, eng, seed, r
             raise err
         raise RuntimeError("rank %d: another rank failed while scanning its windows of this record (its own message "
                            "is on that rank's stderr); nothing was gathered" % rank)
-    return sdist.gather_rows(rows, n_win, rank, world, W, device=device, want=(rank == 0))
+    return sdist.gather_rows(rows, n_win, rank, world, W, device=device, want=(rank == 0), prepacked=packed)
 
 
 def build_parser():

@@ -75,3 +75,30 @@ def test_chunk_schedule_covers_the_range_and_tapers():
             assert b[-1][1] == 512 and max(nw for _, nw in b) <= 2 * scan.CHUNK_WINDOWS
     assert [nw for _, nw in scan._chunk_bounds(0, 29881)] == [7343, 7343, 7343, 7340, 512]
     assert scan._chunk_bounds(0, 10000, chunk=3000) == [(0, 3000), (3000, 3000), (6000, 3000), (9000, 1000)]
+
+
+def test_chunk_size_must_be_positive(monkeypatch):
+    """A zero or negative explicit chunk (argument or SCANFOLD_CHUNK_WINDOWS) is refused instead of producing range(lo, hi, 0)
+    or an empty schedule (a scan that silently writes no rows)."""
+    import pytest
+    from scanfold_amd import scan
+    with pytest.raises(ValueError):
+        scan._chunk_bounds(0, 100, chunk=-5)
+    monkeypatch.setenv("SCANFOLD_CHUNK_WINDOWS", "0")
+    with pytest.raises(ValueError):
+        scan._chunk_bounds(0, 100)
+    monkeypatch.setenv("SCANFOLD_CHUNK_WINDOWS", "-1")
+    with pytest.raises(ValueError):
+        scan._chunk_bounds(0, 100)
+
+
+def test_gather_rows_takes_a_prepacked_shard_of_the_right_shape_only():
+    import numpy as np
+    import pytest
+    from scanfold_amd import dist as sdist
+    rows = ["1\t120\tx\n", "2\t121\ty\n"]
+    assert sdist.gather_rows(rows, 2, 0, 1, 120) == rows  # one rank: nothing is packed or exchanged
+    # world 2 without a process group cannot gather, but the shape check comes first
+    bad = np.zeros((3, 7), dtype=np.uint8)
+    with pytest.raises(ValueError, match="prepacked"):
+        sdist.gather_rows(rows[:1], 2, 0, 2, 120, prepacked=bad)

@@ -68,6 +68,41 @@ def test_bench_single_rank_over_rccl_cfg2():
     assert out["roofline"]["launches"] == 1 and out["roofline"]["folds_per_launch"] == 30659
 
 
+def test_bench_two_ranks_on_gpu0_over_gloo_cfg2():
+    """bench.py with world == 2 on REAL device tensors (the code the driver's multi-GPU run is the first to execute with
+    world > 1): both ranks on GPU 0 — RCCL refuses two ranks on one device, so the collective runs over gloo, staged through
+    the host for the exchange only (SCANFOLD_DIST_BACKEND=gloo, dist.gather_records) — `pack_records` on the device, one
+    all-gather, `merge_shards`; the verified windows come from BOTH shards of the gathered tensor and the elapsed time in the
+    line is the maximum over the ranks."""
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--no-live-counters", "--no-cpu-baseline", "--config", "cfg2"]
+    env = dict(os.environ, SCANFOLD_DIST_BACKEND="gloo", SCANFOLD_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("SCANFOLD_BENCH_FORCE_DIST", None)
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["config"]["windows"] == 989
+    gc = out["gather_check"]
+    assert gc is not None and gc["backend"] == "gloo" and gc["ranks"] == 2 and gc["windows"] == 989
+    assert gc["shard_ranges"] == [[0, 495], [495, 989]]
+    assert gc["rank0_shard_equals_its_device_tensors"] is True
+    assert out["verified_windows"] == 64 and out["verified_mismatches"] == 0 and out["device_status"] == 0
+    per_shard = gc["verified_windows_per_shard"]
+    assert len(per_shard) == 2 and min(per_shard) >= 30 and sum(per_shard) == 64
+    assert "gathered records" in out["verified_against"]
+    assert len(gc["rank_elapsed_s"]) == 2 and gc["elapsed_is_max_over_ranks"] is True
+    assert abs(out["ms_per_step"] - max(gc["rank_elapsed_s"]) / 2 * 1e3) < 1e-6
+    assert abs(out["value"] - 989 * 2 / max(gc["rank_elapsed_s"])) < 1e-6 * out["value"]
+    # rank 0's kernel profile is its own shard's: 495 windows x 31 folds per launch
+    assert out["roofline"]["folds_per_launch"] == 495 * 31
+
+
 def test_all_n_stretch_inside_a_transcript(gpu_engine, oracle):
     """ScanFold-Scan.py:374-380 on the engine: windows that are 120 x N get the literal row, the windows that overlap the
     stretch partly — N folds as a non-pairing nucleotide and is a fifth symbol for the device dinucleotide shuffle — equal

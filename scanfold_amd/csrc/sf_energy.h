@@ -12,6 +12,7 @@
 // reverse pair type: CG <-> GC, GU <-> UG, AU <-> UA; 0 and the non-standard type 7 (a pair forced by a constraint) map to themselves
 __device__ __forceinline__ int sfd_rtype(int t) { return (t && t < 7) ? (((t - 1) ^ 1) + 1) : t; }
 __device__ __forceinline__ int sfd_min(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ short sfd_min16(short a, short b) { return a < b ? a : b; }  // v_min_i16: full rate (32-bit v_min_i32 is half-rate on MI355X)
 __device__ __forceinline__ int sfd_max(int a, int b) { return a > b ? a : b; }
 
 // S points at 1-based codes (S[1..W]); the loop closed by (i,j) has j-i-1 unpaired bases.

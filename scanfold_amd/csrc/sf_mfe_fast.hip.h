@@ -44,6 +44,7 @@
 // on the storage width.  INF is SF_INF16; any sum above SF_FAST_THRESH means "no structure" — parameter
 // sets whose entries exceed SF_FAST_MAXPARAM in magnitude are routed to the int32 kernel entirely.
 #pragma once
+#include <type_traits>
 #include "sf_energy.h"
 #include "sf_pk16.h"
 
@@ -55,6 +56,12 @@
 #define SF_FAST_CHUNK_D0 36
 #ifndef SF_FAST_ROWTAB
 #define SF_FAST_ROWTAB 1  // rolling-row offsets from a table (scalar loads, SfFastRows) instead of per-row ring arithmetic
+#endif
+#ifndef SF_FAST_UNPACK
+#define SF_FAST_UNPACK 1  // split steps (W = 120 instantiation): the generic-loop recurrence on full-rate 16-bit instructions (SfHU)
+#endif
+#ifndef SF_UNP_PB
+#define SF_UNP_PB 4  // size pairs per batch of reads in the unpacked recurrence (3 / 4 / 6 / 12: 58.0 / 57.5 / 58.6 / 58.3 ms per 262 144 folds)
 #endif
 #define SF_FAST_SPLIT 1  // long diagonals: the idle second wave of a group takes part of the cell's work
 #define SF_FAST_DML2 1   // ... and the first runs the multiloop split two cells per lane, the lanes in chunks over the terms
@@ -458,6 +465,16 @@ static inline void sf_emul_check_ci_row(const int16_t *row_ptr, long lane_entrie
 //                dependent LDS round trips
 enum { SF_SEC_P1 = 1, SF_SEC_HELP = 2, SF_SEC_DML = 4, SF_SEC_FIN = 8, SF_SEC_C0 = 16, SF_SEC_ALL = 31, SF_SEC_PRE = 32,
        SF_SEC_POST = 64 };
+// UNP (the split steps of the W = 120 instantiation): the per-size minima of the generic-loop recurrence one int16 per register
+// instead of two.  On MI355X every packed (VOP3P) instruction and the v_lshl_or that packs two 16-bit reads issue at half the rate
+// of the 16-bit VOP2 forms v_min_i16 / v_add_u16 (profiles/r04/mfe_issue_rates.json), so a size pair costs 5 half-rate + 1
+// full-rate vector instructions packed and 7 full-rate ones unpacked: 10.6 against 7.4 ns of a SIMD's vector time.  27
+// registers instead of 14 — which only the main waves of the split steps can afford (no special / bulge / 1xn block there): the
+// kernel converts the state once, at the first split step, and runs those steps as a loop of their own (see the kernel).
+// No saturation is needed: every size exists on these diagonals (no guarded weights), and INF16 + a parameter < 32767.
+struct SfHU {
+  short v[27];  // v[x]: minimum over the generic candidates of total size x + 4
+};
 struct SfPub {
   uint32_t a;  // (mismatchI, mismatch1nI) of the reversed pair: what CI and C1N add to c
   uint32_t b;  // (MLstem + TerminalAU + MLintern, ExtLoop + TerminalAU): what fML and the scratch add to c
@@ -470,9 +487,11 @@ struct SfPub {
 // decides per instantiation (measured: +4 % at W = 120 / 200, +3 % at W = 128; the merged-helper instantiation lost 1-2 % while it
 // spilled and gains 1-3 % since the round-4 pins — W = 64 +1.0, 77 +1.8, 100 +1.4, 117 +3.1 %; the generic wide instantiation, which
 // still spills, keeps the arithmetic)
-template <bool G, int WT, int SEC, bool CH = false, bool FOLD = false, int UCAP = SFD_MAXLOOP, int TBLK = 1, bool MGH = false>
+// @section cell_setup
+template <bool G, int WT, int SEC, bool CH = false, bool FOLD = false, int UCAP = SFD_MAXLOOP, int TBLK = 1, bool MGH = false,
+          bool UNP = false>
 __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, const int i, const bool valid,
-                                             const int slot2, const int slotd, uint32_t (&HP)[14], int &ovf,
+                                             const int slot2, const int slotd, uint32_t (&HP)[14], SfHU &HU, int &ovf,
                                              const bool final_fml, const int fnb, int &fpart, int &dec, int &eh, int &e0,
                                              int &dprev, SfPub &pub, const int dml_lo = SFD_TURN + 1,
                                              const int dml_hi = 1 << 20) {
@@ -517,6 +536,7 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
     if (type == 7) { type = 0; ovf = 1; }
   }
   const int si1 = S[i + 1], sj1 = S[j - 1];
+// @section publish_terms
   if ((SEC & SF_SEC_PRE) && type) {
     const int tr = X.tRPair[S[i] * 8 + S[j]];
     const int sp1 = S[i - 1], sq1 = S[j + 1];
@@ -530,6 +550,7 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
     pub.b = sf_pk(stem + tau_in + X.MLintern, ext + tau_in);
     pub.tau = tau_in;
   }
+// @section cell_setup
 // first entry of diagonal dd.  Triangle without diagonals 0..3: sum_{k=4}^{dd-1} (W-k); FOLD: see the file header
 // (triangle: a diagonal of odd length W-dd is followed by one unused entry, so every diagonal starts at an even index and two
 // neighbouring cells (2p, 2p+1) of a diagonal are ONE aligned 32-bit word — what sf_fast_dml2 reads)
@@ -550,8 +571,56 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
 #define ROWB_BN(u) (TBL ? (((u)&1) ? rbn_o[(u) >> 1] : rbn_e[(u) >> 1]) : 4 * ROW(u))
 #define CIROW(u) ((const int16_t *)((const char *)X.CI + ROWB_CI(u)))
 
+// @section generic_recurrence
   if (SEC & SF_SEC_P1) {
   // ---- pass 1 (every cell): per-size minima of the generic interior candidates ----
+  if (UNP) {
+    static_assert(!UNP || (!G && !CH && !FOLD), "the unpacked recurrence exists for the all-sizes code of the narrow kernel only");
+    const int32_t *const nin = Fc->NIN;  // wave-uniform: scalar loads of whole runs of the table
+    // every candidate read of a batch is issued before the first is used: a pass is SF_UNP_PB-pair batches = that many dependent
+    // LDS round trips — under load the round trip, not the arithmetic, is what a main wave's step consists of
+    short r30a = 0, r30b = 0;
+    {
+      const int16_t *row = CIROW(30) + i0;
+      r30a = row[3]; r30b = row[29];
+    }
+    constexpr int PB = SF_UNP_PB;
+#pragma unroll
+    for (int pb = 12; pb >= 1; pb -= PB) {  // descending: v[x - 2] is still the enclosed cell's
+      short a3[PB], au[PB], b3[PB], bu[PB];
+#pragma unroll
+      for (int k = 0; k < PB; k++) {
+        if (pb - k >= 1) {
+          const int u = 2 * (pb - k) + 4;
+          const int16_t *rb = CIROW(u + 1) + i0, *ra = rb + RW;  // row u is the row after row u + 1 (mirror row at the ring's seam)
+#ifdef SF_EMUL
+          sf_emul_check_ci_row(ra, i0, RW, FOLD); sf_emul_check_ci_row(rb, i0, RW, FOLD);
+#endif
+          a3[k] = ra[3]; au[k] = ra[u - 1];  // size u:     u1 = 2, u2 = 2
+          b3[k] = rb[3]; bu[k] = rb[u];      // size u + 1
+        }
+      }
+      if (pb == 12) {
+        const short e = (short)(sf_opaque16(sfd_min16(r30a, r30b)) + (short)nin[26]);
+        HU.v[26] = sf_opaque16(sfd_min16(e, HU.v[24]));
+      }
+#pragma unroll
+      for (int k = 0; k < PB; k++) {
+        if (pb - k >= 1) {
+          const int x = 2 * (pb - k);  // size u = x + 4
+          const short ea = (short)(sf_opaque16(sfd_min16(a3[k], au[k])) + (short)nin[x]);
+          const short eb = (short)(sf_opaque16(sfd_min16(b3[k], bu[k])) + (short)nin[x + 1]);
+          HU.v[x + 1] = sf_opaque16(sfd_min16(eb, HU.v[x - 1]));
+          HU.v[x] = sf_opaque16(sfd_min16(ea, HU.v[x - 2]));
+        }
+      }
+    }
+    {
+      const int16_t *row = CIROW(5) + i0;
+      HU.v[1] = (short)(sfd_min16((short)row[3], (short)row[4]) + (short)nin[1]);
+      HU.v[0] = (short)((short)(CIROW(4) + i0)[3] + (short)nin[0]);
+    }
+  } else {
   if (G) {
 #pragma unroll
     for (int u = 30; u >= 6; --u) {
@@ -599,9 +668,11 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
     HSET(1, sfd_min(row[3], row[4]) + SF_UNI(uNIN, 1));
   }
   if (!G || (UCAP >= 4 && umax >= 4)) HSET(0, (CIROW(4) + i0)[3] + SF_UNI(uNIN, 0));
+  }
 
   }
 
+// @section special_loops
   // ---- special loops, bulges, 1 x n loops (pairable cells): eh ----
   if (SEC & SF_SEC_HELP) {
     eh = SF_FAST_BIG;
@@ -662,6 +733,7 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
         const int tb = RP[S[i + 4] * 8 + S[j - 3]];  // (i+4, j-3); sp1 = S[i+3], sq1 = S[j-2]
         eh = sfd_min(eh, row[2 * 4] + m23 + X.t23in[SF_TIDX(tb, S[j - 2], S[i + 3])]);
       }
+// @section bulge_1xn
       // bulges (size u >= 2) and 1 x n loops (total size u >= 4), one rolling row per u
       int gb = SF_FAST_BIG, g1 = SF_FAST_BIG;
       if (G) {
@@ -749,6 +821,7 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
     }
   }
 
+// @section multiloop_split_1cell
   // ---- multiloop split: before the barrier when the cell is finished by a later call, else after publishing c
   // (fewer values live across it) ----
   auto multiloop_split = [&]() {
@@ -826,6 +899,7 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
   }
     };
 
+// @section hairpin
   // ---- hairpin, generic minima, multiloop closing (pairable cells): e0 ----
   if (SEC & SF_SEC_C0) {
     e0 = SF_FAST_BIG;
@@ -850,9 +924,20 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
           }
         }
       } else e = X.D->hp_init[d - 1] + X.tH[SF_TIDX(type, si1, sj1)];
+// @section generic_minima
       if (!G || umax >= 0) {
         int gg = SF_FAST_BIG;
-        if (G) {
+        if (UNP) {
+          // one size per full-rate add / min; two accumulators
+          const int32_t *const il = Fc->IL;
+          short g0 = (short)(HU.v[2] + (short)il[6]), g1 = (short)(HU.v[3] + (short)il[7]);
+#pragma unroll
+          for (int x = 4; x <= 26; x += 2) {
+            g0 = sfd_min16(g0, sf_opaque16((short)(HU.v[x] + (short)il[x + 4])));
+            if (x + 1 <= 26) g1 = sfd_min16(g1, sf_opaque16((short)(HU.v[x + 1] + (short)il[x + 5])));
+          }
+          gg = sfd_min16(g0, g1);
+        } else if (G) {
 #pragma unroll
           for (int u = 6; u <= 30; ++u)
             if (u <= UCAP && u <= umax) gg = sfd_min(gg, HGET(u - 4) + SF_UNI(uIL, u));
@@ -867,6 +952,7 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
         }
         e = sfd_min(e, gg + X.tI[SF_TIDX(type, si1, sj1)]);
       }
+// @section multiloop_closing
       // multiloop closed by (i,j)
       {
         const int tr = X.tRPair[S[i] * 8 + S[j]];  // type != 0 here: the reversed type of the cell's own pair
@@ -876,6 +962,7 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
       e0 = e;
     }
   }
+// @section finish_publish
   if ((SEC & SF_SEC_DML) && !(SEC & SF_SEC_FIN)) multiloop_split();
 
   if (!(SEC & SF_SEC_FIN)) return;
@@ -943,6 +1030,7 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
 #undef BNROWB
 }
 
+// @section wave_min
 // minimum over the 64 lanes of a wave, returned in every lane.  DPP row operations + one readlane: no LDS
 // round trips (the generic __shfl_xor butterfly lowers to ds_bpermute, ~6 dependent LDS-crossbar trips).
 __device__ __forceinline__ int sf_wave_min(int v) {
@@ -968,6 +1056,7 @@ __device__ __forceinline__ uint32_t sf_wave_next(uint32_t v) {
 #endif
 }
 
+// @section multiloop_split_2cell
 // Multiloop split of a WHOLE diagonal by one wave (split steps of the narrow kernel: the diagonal's n = W-d <= 62 cells are
 // all in this wave): dec[i] = min_{m=4}^{d-5} fML[i, i+m] + fML[i+m+1, j] for every cell, returned to the lane that owns the cell.
 // The one-cell-per-lane form keeps (W-d)/64 of the lanes busy and issues two 16-bit reads and ~4 vector instructions per
@@ -1024,16 +1113,20 @@ __device__ __forceinline__ int sf_fast_dml2(const SfFastCtx &X, const int d, con
     const uint32_t w = sf_ldw(X.fML + 2 * q + d - 5);
     acc0 = sf_pkmin(acc0, sf_pkadd(a, (sf_wave_next(w) << 16) | (w >> 16)));
   }
+  // the chunks' partial minima meet by butterfly: lanes l ^ 32, l ^ 16, l ^ 8 — on the vector ALU (sf_pkmin_xor*: v_permlane32_swap /
+  // v_permlane16_swap / a DPP row rotate, gfx950), not through the LDS crossbar: __shfl_xor is a ds_bpermute, and each of the one
+  // to three of them was a dependent LDS round trip in the middle of the main wave's step
   uint32_t acc = sf_pkmin(acc0, acc1);
-  acc = sf_pkmin(acc, __shfl_xor(acc, 32));
-  if (lg <= 4) acc = sf_pkmin(acc, __shfl_xor(acc, 16));
-  if (lg <= 3) acc = sf_pkmin(acc, __shfl_xor(acc, 8));
+  acc = sf_pkmin_xor32(acc);
+  if (lg <= 4) acc = sf_pkmin_xor16(acc);
+  if (lg <= 3) acc = sf_pkmin_xor8(acc);
   // the cell's owner fetches its pair's result (every chunk holds it now) and takes its half
   const int i0 = valid ? i_own - 1 : 0;
   const uint32_t r = __shfl(acc, i0 >> 1);
   return (i0 & 1) ? sf_hi(r) : sf_lo(r);
 }
 
+// @section traceback
 // c[i,j] from the scratch (which may hold c + ExtLoop, see SfFastCtx::cg_ext)
 __device__ __forceinline__ int sf_fast_c(const SfFastCtx &X, const int16_t *tExt, const int i, const int j) {
   const int W = X.W;
@@ -1188,6 +1281,7 @@ __device__ inline int sf_fast_traceback(const SfFastCtx &X, const int32_t *f5s, 
 }
 
 
+// @section exterior_sweep_native
 // NG = threads per diagonal group.  The workgroup has two groups: group 0 handles the even diagonals, group 1
 // the odd ones.  c[.,.] of diagonal d+1 does not depend on diagonal d (an enclosed pair spans at most d-1, the
 // multiloop split of d+1 reads fML spans <= d-3), only fML[d+1] needs its two neighbours on d — so the pair
@@ -1304,6 +1398,7 @@ __device__ __forceinline__ void sf_fast_exterior(const SfFastCtx &X, const int W
   }
 }
 
+// @section trailing_sweep
 // Trailing exterior sweep.  A fold whose structure is not wanted does not run the 5' -> 3' sweep at its end (one wave
 // working for ~50 k cycles while the other three wait: 8 % of a fold's residency) and does not hand its scratch to the
 // next fold either (round 2: two scratch tables per workgroup, 28 MB for the grid against 32 MB of L2, 65 GB of
@@ -1371,6 +1466,7 @@ __device__ __forceinline__ void sf_trail_result(const SfTrail<NQ> &T, const int 
 }
 
 
+// @section kernel_prologue
 // the poison build's pattern for int16 entry x (see PZ below)
 __device__ __forceinline__ int16_t sf_poison16(const int poison, const int x) {
   const int k = poison == 5 ? 1 + (int)(((uint32_t)x * 2654435761u) >> 30) : poison;
@@ -1433,6 +1529,8 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
   X.S = S;
   X.D = D; X.F = F; X.R = Rows; X.W = W; X.fold = FOLD; X.maxd = D->max_pair_dist;
   constexpr bool MERGE = MG && SF_HELP_MERGE && (NG == 128);
+  // the split steps' generic-loop recurrence with its state unpacked (SfHU): the W = 120 instantiation
+  constexpr bool UNPK = SF_FAST_UNPACK && (NG == 128) && (WT == 120) && SF_FAST_DML2;
   // rolling-row offsets from SfFastRows (see sf_fast_cell): 1 = yes, 2 = yes + the long read batches of the generic merged-helper
   // instantiation, 0 = no (the generic wide kernel)
   constexpr int TBLK = WT > 0 ? 1 : (NG == 128 ? (MG ? 2 : 1) : 0);
@@ -1521,6 +1619,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
   // The index of the NEXT fold is requested at the start of a fold (one atomic by thread 0), parked in LDS two steps
   // later, and read by everybody one step after that: its latency is never waited for.
   int *const next_slot = (int *)(smem + Lo.off_next);
+// @section fold_prologue
   int seq = blockIdx.x;
   while (seq < n) {
     const uint8_t *src = seqs + (size_t)seq * W;
@@ -1586,6 +1685,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
 
     // this thread's diagonal in the step that starts at the even diagonal d0 is d0 + grp
     int slot2 = (SFD_TURN + 1 + grp - 2) % SF_FAST_NR, slotd = (SFD_TURN + 1 + grp) % SF_FAST_NR;
+// @section cell_list
     // Merged helper: the cells of the diagonals dd0 and dd0+1 that can pair, as a helper wave sees them (lane -> mirror
     // cell; i is the same on both diagonals since (dd0 + 1) >> 1 == dd0 >> 1).  Entry = i, +128 for the odd diagonal,
     // even diagonal first; byte 127 of the buffer = the number of entries (<= 124).  Built by wave 3 one step ahead
@@ -1605,7 +1705,13 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
       if (tB) list[cA + __popcll(mB & below)] = (uint8_t)(iH | 128);
       if (lane == 0) list[127] = (uint8_t)(cA + __popcll(mB));
     };
-    for (int d0 = SFD_TURN + 1; d0 < W; d0 += 2) {
+// @section step_control
+    // One step = the diagonals d0 (even group) and d0 + 1 (odd group).  P2 (UNPK instantiations): the split steps as a loop of
+    // their own, with the generic-loop recurrence's state unpacked (SfHU) — as a separate loop so that the 27 registers are live
+    // only where no special / bulge / 1xn block competes for them.
+    SfHU HU;
+    auto step = [&](const int d0, auto p2_tag) {
+      constexpr bool P2 = decltype(p2_tag)::value;
       const int d = d0 + grp;
       if (d0 == SFD_TURN + 1 + 2 && tid == 0) *next_slot = fetched;            // the barriers of this step publish it
       if (d0 == SFD_TURN + 1 + 4) next_seq = SF_WAVE_UNIFORM(*next_slot);
@@ -1614,7 +1720,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
       // those cells, while the first does the generic-loop recurrence and the multiloop split; the partial
       // result crosses in LDS (in the C1N entry the cell will publish, unread until the next step) at a barrier,
       // then the first wave finishes the cell.  The dependent chain of such a step is ~45 % shorter.
-      const bool split = d0 >= split_d0;
+      const bool split = P2 || (!UNPK && d0 >= split_d0);  // (UNPK: the first loop ends where the split steps begin)
       // helper lanes mirror a main lane 64 away: NG = 128: wave 1 -> wave 0; NG = 256: wave 0 -> wave 1, wave 3 -> wave 2
       const bool narrow = NARROW && d0 >= narrow_d0;
       if (NARROW && d0 == narrow_d0) {
@@ -1670,31 +1776,31 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
           if (k < sweep_rows) sf_trail_load<NQ>(X.cg, W, tid & 63, T.row - k, dc[k]);
       }
       if (__ballot(valid)) {
-        if (d0 < 8) sf_fast_cell<true, WT, SF_SEC_ALL, false, FOLD, 1>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
-        else if (d0 < SF_FAST_TINY_D0) sf_fast_cell<true, WT, SF_SEC_ALL, false, FOLD, 5>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
-        else if (d0 < SF_FAST_CHUNK_D0) sf_fast_cell<false, WT, SF_SEC_ALL, true, FOLD, SFD_MAXLOOP, TBLK>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
-        else if (!split) sf_fast_cell<false, WT, SF_SEC_ALL, false, FOLD, SFD_MAXLOOP, TBLK>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
+        if (!P2 && d0 < 8) sf_fast_cell<true, WT, SF_SEC_ALL, false, FOLD, 1>(X, d, i, valid, slot2, slotd, H, HU, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
+        else if (!P2 && d0 < SF_FAST_TINY_D0) sf_fast_cell<true, WT, SF_SEC_ALL, false, FOLD, 5>(X, d, i, valid, slot2, slotd, H, HU, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
+        else if (!P2 && d0 < SF_FAST_CHUNK_D0) sf_fast_cell<false, WT, SF_SEC_ALL, true, FOLD, SFD_MAXLOOP, TBLK>(X, d, i, valid, slot2, slotd, H, HU, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
+        else if (!P2 && !split) sf_fast_cell<false, WT, SF_SEC_ALL, false, FOLD, SFD_MAXLOOP, TBLK>(X, d, i, valid, slot2, slotd, H, HU, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
         else if (DML4 && narrow) {
           // terms m = 4 .. d-5: main [4, cA), wave 2 [cA, cB), wave 3 [cB, d-5]
           const int nmain = dml_terms / 5, cA = SFD_TURN + 1 + nmain, cB = cA + (dml_terms - nmain + 1) / 2;
           uint32_t *const xa = (uint32_t *)X.BN;
           if (dmlw) {
             const bool wB = tg >= 192;
-            sf_fast_cell<false, WT, SF_SEC_DML, false, FOLD, SFD_MAXLOOP, TBLK>(X, d, i, valid, slot2, slotd, H, ovf, false, fnb, fpart, dec, eh, e0, dprev, pub, wB ? cB : cA, wB ? (1 << 20) : cB - 1);
+            sf_fast_cell<false, WT, SF_SEC_DML, false, FOLD, SFD_MAXLOOP, TBLK>(X, d, i, valid, slot2, slotd, H, HU, ovf, false, fnb, fpart, dec, eh, e0, dprev, pub, wB ? cB : cA, wB ? (1 << 20) : cB - 1);
             if (valid) xa[(grp * 16 + (wB ? 1 : 0)) * (W - 4) + 100 + (tg & 63)] = (uint32_t)sfd_min(dec, 32000);
           } else if (!helper) {
-            sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_DML | SF_SEC_PRE, false, FOLD, SFD_MAXLOOP, TBLK>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub, SFD_TURN + 1, cA - 1);
+            sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_DML | SF_SEC_PRE, false, FOLD, SFD_MAXLOOP, TBLK>(X, d, i, valid, slot2, slotd, H, HU, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub, SFD_TURN + 1, cA - 1);
           } else {
-            sf_fast_cell<false, WT, SF_SEC_HELP, false, FOLD, SFD_MAXLOOP, TBLK>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
+            sf_fast_cell<false, WT, SF_SEC_HELP, false, FOLD, SFD_MAXLOOP, TBLK>(X, d, i, valid, slot2, slotd, H, HU, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
             if (valid) X.BN[2 * (slotd * (W - 4) + i - 1)] = (int16_t)sfd_min(eh, 32000);
           }
         }
         else if (!helper) {
-          if (SHARE) sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_DML | SF_SEC_PRE, false, FOLD, SFD_MAXLOOP, TBLK>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub, SFD_TURN + 1, dml_cut - 1);
+          if (SHARE) sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_DML | SF_SEC_PRE, false, FOLD, SFD_MAXLOOP, TBLK>(X, d, i, valid, slot2, slotd, H, HU, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub, SFD_TURN + 1, dml_cut - 1);
           else if (DML2) {
             dec = sf_fast_dml2<WT>(X, d, tid & 63, i, valid);
-            sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_PRE, false, FOLD, SFD_MAXLOOP, TBLK>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
-          } else sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_DML | SF_SEC_PRE, false, FOLD, SFD_MAXLOOP, TBLK>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
+            sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_PRE, false, FOLD, SFD_MAXLOOP, TBLK, false, P2>(X, d, i, valid, slot2, slotd, H, HU, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
+          } else sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_DML | SF_SEC_PRE, false, FOLD, SFD_MAXLOOP, TBLK>(X, d, i, valid, slot2, slotd, H, HU, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
         } else if (MERGE) {
           // Merged helper (W <= 128).  ONE helper wave serves both diagonals of the step: it works on the list of the
           // cells of d0 and d0+1 that can pair (build_list above; 3 of 8 cells, so ordinary sequences fit wave 1's 64
@@ -1714,7 +1820,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
             const int sd1 = sd0 + 1 >= SF_FAST_NR ? 0 : sd0 + 1;
             SfFastCtx Xh = X;
             Xh.BN = X.BN + 2 * g * (W - 4);
-            sf_fast_cell<false, WT, SF_SEC_HELP, false, FOLD, SFD_MAXLOOP, TBLK, true>(Xh, d0 + g, iC, vC, s2, sd0, H, ovf, false, fnb, fpart, dec, eh, e0, dprev, pub);
+            sf_fast_cell<false, WT, SF_SEC_HELP, false, FOLD, SFD_MAXLOOP, TBLK, true>(Xh, d0 + g, iC, vC, s2, sd0, H, HU, ovf, false, fnb, fpart, dec, eh, e0, dprev, pub);
             if (vC) X.BN[2 * ((g ? sd1 : sd0) * (W - 4) + iC - 1)] = (int16_t)sfd_min(eh, 32000);
           }
         } else {
@@ -1722,13 +1828,13 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
           // step, and rewritten by nobody but the cell's own lane): eh in the CB half of its word, its part of the
           // multiloop split in its CI entry
           if (SHARE) {
-            sf_fast_cell<false, WT, SF_SEC_HELP | SF_SEC_DML, false, FOLD, SFD_MAXLOOP, TBLK>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub, dml_cut);
+            sf_fast_cell<false, WT, SF_SEC_HELP | SF_SEC_DML, false, FOLD, SFD_MAXLOOP, TBLK>(X, d, i, valid, slot2, slotd, H, HU, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub, dml_cut);
             if (valid) {
               X.BN[2 * (slotd * (W - 4) + i - 1)] = (int16_t)sfd_min(eh, 32000);
               X.CI[slotd * (W - 4) + i - 1] = (int16_t)sfd_min(dec, 32000);
             }
           } else {
-            sf_fast_cell<false, WT, SF_SEC_HELP, false, FOLD, SFD_MAXLOOP, TBLK>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
+            sf_fast_cell<false, WT, SF_SEC_HELP, false, FOLD, SFD_MAXLOOP, TBLK>(X, d, i, valid, slot2, slotd, H, HU, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
             if (valid) X.BN[2 * (slotd * (W - 4) + i - 1)] = (int16_t)sfd_min(eh, 32000);
           }
         }
@@ -1736,6 +1842,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
       if (sweep_now && sweep_rows > 0) sf_trail_rows<NQ, DROWS>(T, tid & 63, sweep_rows, dc);
       // merged helper: wave 3 lists the next step's cells (the barriers of this step order the list before its readers)
       if (MERGE && grp == 1 && tg >= 64 && d0 + 2 >= split_d0 && d0 + 2 < W) build_list(d0 + 2);
+// @section exchange
       if (split) {
         __syncthreads();
         if (!helper && !dmlw && __ballot(valid)) {
@@ -1746,15 +1853,20 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
               dec = sfd_min(dec, sfd_min((int)xa[(grp * 16) * (W - 4) + 100 + (tg & 63)], (int)xa[(grp * 16 + 1) * (W - 4) + 100 + (tg & 63)]));
             } else if (SHARE) dec = sfd_min(dec, (int)X.CI[slotd * (W - 4) + i - 1]);
           }
-          sf_fast_cell<false, WT, SF_SEC_FIN | SF_SEC_POST, false, FOLD, SFD_MAXLOOP, TBLK>(X, d, i, valid, slot2, slotd, H, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
+          sf_fast_cell<false, WT, SF_SEC_FIN | SF_SEC_POST, false, FOLD, SFD_MAXLOOP, TBLK>(X, d, i, valid, slot2, slotd, H, HU, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
         }
       }
       __syncthreads();
+// @section fml_fixup
       // fML on the odd diagonal d0+1 = its provisional value (written by the odd group) min the two neighbours on
       // the even diagonal d0, now final.  The EVEN group does this: the only early reader of fML[d0+1] is the even
       // group's next cell (i-1, j+1), which needs the cells i-1 and i of it — so every even lane finishes BOTH
       // (storing only its own, i) and keeps their minimum in a register.  No second barrier: nothing else reads
       // these entries before several later barriers (the multiloop split of d reads spans <= d-5).
+      // (Round 5 folded this into the even group's NEXT finish — reads issued before the multiloop split, used after it, no separate
+      // phase: bit-exact and 3.5 % SLOWER at every width.  The step stamps say why: with the even group no longer trailing the odd one
+      // by these ~800 cycles, all four waves of a workgroup issue the same LDS bursts at the same time and every phase of every wave
+      // got ~8 % longer — profiles/r05/mfe_step_stamps_lazy_fixup_rejected.txt against mfe_step_stamps_unpacked.txt.)
       if (grp == 0 && valid && !helper && !dmlw) {
         const int d1 = d0 + 1;
         const int fbd = FBASE(d1), fbe = FBASE(d0);
@@ -1774,8 +1886,19 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
       }
       slot2 += 2; if (slot2 >= SF_FAST_NR) slot2 -= SF_FAST_NR;
       slotd += 2; if (slotd >= SF_FAST_NR) slotd -= SF_FAST_NR;
+    };
+    {
+      int d0 = SFD_TURN + 1;
+      const int d_unp = UNPK ? split_d0 : W;
+      for (; d0 < d_unp && d0 < W; d0 += 2) step(d0, std::false_type{});
+      if constexpr (UNPK) {
+#pragma unroll
+        for (int x = 0; x < 27; x++) HU.v[x] = (short)((x & 1) ? (H[x >> 1] >> 16) : (H[x >> 1] & 0xffffu));
+        for (; d0 < W; d0 += 2) step(d0, std::true_type{});
+      }
     }
 
+// @section fold_epilogue
     // ---- exterior loop f5[j] = min(f5[j-1], min_i f5[i-1] + c[i,j] + ExtLoop(i,j)) : wave 0 only ----
     // (sf_fast_exterior: lane = column, rows of c + ExtLoop stream from the scratch a few rows ahead)
     if (ovf) flag[0] = 1;

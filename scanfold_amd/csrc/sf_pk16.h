@@ -41,6 +41,34 @@ __device__ __forceinline__ uint32_t sf_ldw(const int16_t *p) { return *(const ui
 __device__ __forceinline__ void sf_stw(int16_t *p, uint32_t v) { *(uint32_t *)p = v; }
 __device__ __forceinline__ void sf_store_fence() { asm volatile("" ::: "memory"); }  // keeps two b16 stores apart
 #endif
+// Packed-int16 minimum of a lane's value with lane l ^ 32 / l ^ 16 / l ^ 8's — one step of a butterfly all-reduce — without the LDS
+// crossbar (a generic __shfl_xor lowers to ds_bpermute: an LDS round trip).  gfx950: v_permlane32_swap swaps the upper half of one
+// copy with the lower half of another, so the two copies hold (lo, lo) and (hi, hi); v_permlane16_swap the same for the 16-lane
+// rows; lanes 8 apart inside a row meet by a DPP row rotate.
+#ifdef SF_EMUL
+static inline uint32_t sf_pkmin_xor32(uint32_t v) { return sf_pkmin(v, (uint32_t)__shfl_xor((int)v, 32)); }
+static inline uint32_t sf_pkmin_xor16(uint32_t v) { return sf_pkmin(v, (uint32_t)__shfl_xor((int)v, 16)); }
+static inline uint32_t sf_pkmin_xor8(uint32_t v) { return sf_pkmin(v, (uint32_t)__shfl_xor((int)v, 8)); }
+#else
+__device__ __forceinline__ uint32_t sf_pkmin_xor32(uint32_t v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  return sf_pkmin(r[0], r[1]);
+}
+__device__ __forceinline__ uint32_t sf_pkmin_xor16(uint32_t v) {
+  const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+  return sf_pkmin(r[0], r[1]);
+}
+__device__ __forceinline__ uint32_t sf_pkmin_xor8(uint32_t v) {
+  return sf_pkmin(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xF, 0xF, false));  // row_ror:8
+}
+#endif
+// An int16 value the optimiser must take as given: keeps chains of SCALAR 16-bit operations (v_min_i16, v_add_u16: full rate on
+// MI355X) from being re-packed into half-rate v_pk_* instructions behind v_perm packs by the SLP vectoriser (sf_mfe_fast.hip.h, UNP)
+#ifdef SF_EMUL
+static inline short sf_opaque16(short x) { return x; }
+#else
+__device__ __forceinline__ short sf_opaque16(short x) { asm("" : "+v"(x)); return x; }
+#endif
 // the pair (p[0], p[1]); odd = parity of p's int16 index, known at compile time after unrolling
 __device__ __forceinline__ uint32_t sf_ld2(const int16_t *p, const int odd) {
   if (odd) {

@@ -1,0 +1,115 @@
+"""Ablation / variant builds of the library for A/B timing (tools/gpu_mfe_cmp.py picks up every tools/abl_*.so).
+
+    python tools/dev/abl.py NAME [NAME ...]     # builds tools/abl_NAME.so for each, in parallel
+
+A variant is the working tree's scanfold_amd/csrc + include copied to /tmp/abl_NAME with text patches applied (PATCHES below:
+(anchor, replacement) pairs; an anchor must occur exactly once) and / or extra -D flags.  Ablated kernels compute WRONG
+energies on purpose (a section skipped): only their time and counters mean anything.  Never part of the product."""
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+FAST = "scanfold_amd/csrc/sf_mfe_fast.hip.h"
+
+CELLS = "      if (__ballot(valid)) {\n        if (!P2 && d0 < 8)"
+FIN = "        if (!helper && !dmlw && __ballot(valid)) {"
+DML2 = "            dec = sf_fast_dml2<WT>(X, d, tid & 63, i, valid);"
+MAINCALL = ("            sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_PRE, false, FOLD, SFD_MAXLOOP, TBLK, false, P2>(X, d, i, valid, "
+            "slot2, slotd, H, HU, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);")
+MGHCALL = "            sf_fast_cell<false, WT, SF_SEC_HELP, false, FOLD, SFD_MAXLOOP, TBLK, true>(Xh, d0 + g, iC,"
+
+HOST = "scanfold_amd/csrc/scanfold_hip.hip"
+# "stamps": a cycle-stamped diagnostic build.  Lane 0 of every wave of every 64th workgroup adds, per step and wave, the cycles
+# (s_memtime) from the start of the step to: the end of its own pre-barrier work [0], the exit of the exchange barrier [5] (split
+# steps), the end of the finish [1], the exit of the end-of-step barrier [2], the end of the step (after the fML fix-up) [3];
+# [4] counts.  The sums live behind the status word; sf_prof_get dumps them to $SF_STAMP_OUT (tools/dev/stamp_report.py reads it).
+STAMP_PATCHES = [
+    (FAST, "      constexpr bool P2 = decltype(p2_tag)::value;\n      const int d = d0 + grp;\n",
+     "      constexpr bool P2 = decltype(p2_tag)::value;\n      const int d = d0 + grp;\n"
+     "      unsigned long long *const SFP = (unsigned long long *)(status + 64) + (size_t)(((d0 >> 1) * 4 + (tid >> 6)) * 8);\n"
+     "      const bool SFL = (tid & 63) == 0 && (blockIdx.x & 63) == 5;\n"
+     "      const long long SFT0 = SFL ? (long long)clock64() : 0;\n"),
+    (FAST, "      if (split) {\n        __syncthreads();\n        if (!helper && !dmlw && __ballot(valid)) {",
+     "      if (SFL) atomicAdd(SFP + 0, (unsigned long long)(clock64() - SFT0));\n"
+     "      if (split) {\n        __syncthreads();\n        if (SFL) atomicAdd(SFP + 5, (unsigned long long)(clock64() - SFT0));\n"
+     "        if (!helper && !dmlw && __ballot(valid)) {"),
+    (FAST, "      __syncthreads();\n// @section fml_fixup\n",
+     "      if (SFL) atomicAdd(SFP + 1, (unsigned long long)(clock64() - SFT0));\n      __syncthreads();\n"
+     "      if (SFL) atomicAdd(SFP + 2, (unsigned long long)(clock64() - SFT0));\n"),
+    (FAST, "      slot2 += 2; if (slot2 >= SF_FAST_NR) slot2 -= SF_FAST_NR;\n      slotd += 2; if (slotd >= SF_FAST_NR) slotd -= SF_FAST_NR;\n    };",
+     "      if (SFL) { atomicAdd(SFP + 3, (unsigned long long)(clock64() - SFT0)); atomicAdd(SFP + 4, 1ull); }\n"
+     "      slot2 += 2; if (slot2 >= SF_FAST_NR) slot2 -= SF_FAST_NR;\n      slotd += 2; if (slotd >= SF_FAST_NR) slotd -= SF_FAST_NR;\n    };"),
+    (HOST, "    int rc = ensure(g.status, sizeof(int));\n    if (rc) return rc;\n    HIPCHK(hipMemset(g.status.p, 0, sizeof(int)));",
+     "    int rc = ensure(g.status, 65536);\n    if (rc) return rc;\n    HIPCHK(hipMemset(g.status.p, 0, 65536));"),
+    (HOST, "  ProfPair::prof_drain();\n  if (ms) *ms = g.prof_ms;",
+     "  ProfPair::prof_drain();\n  if (const char *so = getenv(\"SF_STAMP_OUT\")) {\n"
+     "    static unsigned long long hb[64 * 4 * 8];\n    HIPCHK(hipMemcpy(hb, (char *)g.status.p + 256, sizeof hb, hipMemcpyDeviceToHost));\n"
+     "    HIPCHK(hipMemset((char *)g.status.p + 256, 0, sizeof hb));\n    if (FILE *f = fopen(so, \"w\")) {\n"
+     "      for (int k = 0; k < 64 * 4; k++) { for (int q = 0; q < 8; q++) fprintf(f, \"%llu \", hb[k * 8 + q]); fprintf(f, \"\\n\"); }\n"
+     "      fclose(f);\n    }\n  }\n  if (ms) *ms = g.prof_ms;"),
+    (HOST, "  g.prof_on = true;  // from now on launch_mfe brackets the dominant kernel with two events",
+     "  g.prof_on = true;\n  HIPCHK(hipMemset((char *)g.status.p + 256, 0, 64 * 4 * 8 * 8));"),
+]
+
+VARIANTS = {
+    "stamps": (STAMP_PATCHES, []),
+    # name: (patches, flags)
+    "head": ([], []),
+    "nb6": ([(FAST, "#define SF_HELP_NB_128 4", "#define SF_HELP_NB_128 6")], []),
+    "nb8": ([(FAST, "#define SF_HELP_NB_128 4", "#define SF_HELP_NB_128 8")], []),
+    "nb2": ([(FAST, "#define SF_HELP_NB_128 4", "#define SF_HELP_NB_128 2")], []),
+    "pb4": ([], ["-DSF_UNP_PB=4"]),
+    # artificial skew between the two diagonal groups of a workgroup (the odd group starts its step later)
+    "skew4": ([(FAST, "      constexpr bool P2 = decltype(p2_tag)::value;\n      const int d = d0 + grp;\n", "      constexpr bool P2 = decltype(p2_tag)::value;\n      const int d = d0 + grp;\n      if (grp == 1) __builtin_amdgcn_s_sleep(4);\n")], []),
+    "skew12": ([(FAST, "      constexpr bool P2 = decltype(p2_tag)::value;\n      const int d = d0 + grp;\n", "      constexpr bool P2 = decltype(p2_tag)::value;\n      const int d = d0 + grp;\n      if (grp == 1) __builtin_amdgcn_s_sleep(12);\n")], []),
+    "skew4e": ([(FAST, "      constexpr bool P2 = decltype(p2_tag)::value;\n      const int d = d0 + grp;\n", "      constexpr bool P2 = decltype(p2_tag)::value;\n      const int d = d0 + grp;\n      if (grp == 0) __builtin_amdgcn_s_sleep(4);\n")], []), "pb6": ([], ["-DSF_UNP_PB=6"]), "pb12": ([], ["-DSF_UNP_PB=12"]),
+    "nounpack": ([], ["-DSF_FAST_UNPACK=0"]),
+    # phases: which steps cost what (the other phase keeps its barriers and control code)
+    "nosplitwork": ([(FAST, CELLS, "      if (!split && __ballot(valid)) {\n        if (!P2 && d0 < 8)"),
+                     (FAST, FIN, "        if (false) {")], []),
+    "nounsplitwork": ([(FAST, CELLS, "      if (split && __ballot(valid)) {\n        if (!P2 && d0 < 8)")], []),
+    # split steps, by role
+    "nodml2": ([(FAST, DML2, "            dec = SF_INF16;")], []),
+    "nomainp1": ([(FAST, MAINCALL, MAINCALL.replace("SF_SEC_P1 | SF_SEC_C0 | SF_SEC_PRE", "SF_SEC_PRE"))], []),
+    "nomgh": ([(FAST, MGHCALL, "            if (false) " + MGHCALL.strip())], []),
+    "nofin": ([(FAST, FIN, "        if (false) {")], []),
+    # what the main waves' post-barrier work costs, piece by piece
+    "nofixupS": ([(FAST, "      if (grp == 0 && valid && !helper && !dmlw) {", "      if (!split && grp == 0 && valid && !helper && !dmlw) {")], []),
+    "finlite": ([(FAST, "  if ((SEC & SF_SEC_POST) && type) {\n    X.CI[rbd] = (int16_t)(c + sf_lo(pub.a));",
+                  "  if ((SEC & SF_SEC_POST) && type) {\n    f = c + sf_lo(pub.b);\n    cx = sfd_min(c + sf_hi(pub.b), SF_INF16);\n  } else if ((SEC & SF_SEC_POST) && !type) {\n  } else if (false) {\n    X.CI[rbd] = (int16_t)(c + sf_lo(pub.a));")], []),
+    "noscratchS": ([(FAST, "  X.cg[SF_CGIDX(i, j)] = (int16_t)cx;", "  if (!(SEC & SF_SEC_POST)) X.cg[SF_CGIDX(i, j)] = (int16_t)cx;")], []),
+    # the phases before the split steps
+    "noG": ([(FAST, CELLS, "      if (d0 >= SF_FAST_TINY_D0 && __ballot(valid)) {\n        if (!P2 && d0 < 8)")], []),
+    "noCH": ([(FAST, CELLS, "      if ((d0 < SF_FAST_TINY_D0 || d0 >= SF_FAST_CHUNK_D0) && __ballot(valid)) {\n        if (!P2 && d0 < 8)")], []),
+    "noU36": ([(FAST, CELLS, "      if ((d0 < SF_FAST_CHUNK_D0 || split) && __ballot(valid)) {\n        if (!P2 && d0 < 8)")], []),
+}
+
+
+def build(name):
+    patches, flags = VARIANTS[name]
+    tmp = "/tmp/abl_" + name
+    shutil.rmtree(tmp, ignore_errors=True)
+    os.makedirs(tmp + "/scanfold_amd")
+    shutil.copytree(os.path.join(ROOT, "scanfold_amd", "csrc"), tmp + "/scanfold_amd/csrc", ignore=shutil.ignore_patterns("*.so"))
+    shutil.copytree(os.path.join(ROOT, "include"), tmp + "/include")
+    for rel, anchor, repl in patches:
+        path = os.path.join(tmp, rel)
+        s = open(path).read()
+        if s.count(anchor) != 1:
+            return name, "anchor occurs %d times: %r" % (s.count(anchor), anchor[:60])
+        open(path, "w").write(s.replace(anchor, repl))
+    out = os.path.join(ROOT, "tools", "abl_%s.so" % name)
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value"] + flags + \
+          ["-o", out, tmp + "/scanfold_amd/csrc/scanfold_hip.hip"]
+    p = subprocess.run(cmd, capture_output=True, text=True)
+    return name, "ok" if p.returncode == 0 else p.stderr[-1500:]
+
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or sorted(VARIANTS)
+    with ThreadPoolExecutor(max_workers=6) as ex:
+        for name, msg in ex.map(build, names):
+            print(name, msg)

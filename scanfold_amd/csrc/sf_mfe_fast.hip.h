@@ -60,6 +60,9 @@
 #ifndef SF_FAST_UNPACK
 #define SF_FAST_UNPACK 1  // split steps (W = 120 instantiation): the generic-loop recurrence on full-rate 16-bit instructions (SfHU)
 #endif
+#ifndef SF_LOOPS_BY_KIND
+#define SF_LOOPS_BY_KIND 1
+#endif
 #ifndef SF_UNP_PB
 #define SF_UNP_PB 4  // size pairs per batch of reads in the unpacked recurrence (3 / 4 / 6 / 12: 58.0 / 57.5 / 58.6 / 58.3 ms per 262 144 folds)
 #endif
@@ -1531,6 +1534,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
   constexpr bool MERGE = MG && SF_HELP_MERGE && (NG == 128);
   // the split steps' generic-loop recurrence with its state unpacked (SfHU): the W = 120 instantiation
   constexpr bool UNPK = SF_FAST_UNPACK && (NG == 128) && (WT == 120) && SF_FAST_DML2;
+  constexpr bool BYKIND = SF_LOOPS_BY_KIND != 0;  // the steps of a fold as one loop per kind of step (see the loops)
   // rolling-row offsets from SfFastRows (see sf_fast_cell): 1 = yes, 2 = yes + the long read batches of the generic merged-helper
   // instantiation, 0 = no (the generic wide kernel)
   constexpr int TBLK = WT > 0 ? 1 : (NG == 128 ? (MG ? 2 : 1) : 0);
@@ -1706,12 +1710,14 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
       if (lane == 0) list[127] = (uint8_t)(cA + __popcll(mB));
     };
 // @section step_control
-    // One step = the diagonals d0 (even group) and d0 + 1 (odd group).  P2 (UNPK instantiations): the split steps as a loop of
-    // their own, with the generic-loop recurrence's state unpacked (SfHU) — as a separate loop so that the 27 registers are live
-    // only where no special / bulge / 1xn block competes for them.
+    // One step = the diagonals d0 (even group) and d0 + 1 (odd group).  The body is instantiated once per kind of step (PH).
     SfHU HU;
-    auto step = [&](const int d0, auto p2_tag) {
-      constexpr bool P2 = decltype(p2_tag)::value;
+    auto step = [&](const int d0, auto phase_tag) {
+      // PH: the kind of step this instantiation of the body is for (BYKIND: one loop per kind, see below) — 3: d0 < 12 (size-tested
+      // code), 4: 12 <= d0 < 36 (guarded code), 1: the unsplit steps from d0 = 36 on, 2: the split steps; 0: any (one loop)
+      constexpr int PH = decltype(phase_tag)::value;
+      constexpr bool P2 = (PH == 2);
+      constexpr bool DO_G = (PH == 0 || PH == 3), DO_CH = (PH == 0 || PH == 4);
       const int d = d0 + grp;
       if (d0 == SFD_TURN + 1 + 2 && tid == 0) *next_slot = fetched;            // the barriers of this step publish it
       if (d0 == SFD_TURN + 1 + 4) next_seq = SF_WAVE_UNIFORM(*next_slot);
@@ -1720,7 +1726,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
       // those cells, while the first does the generic-loop recurrence and the multiloop split; the partial
       // result crosses in LDS (in the C1N entry the cell will publish, unread until the next step) at a barrier,
       // then the first wave finishes the cell.  The dependent chain of such a step is ~45 % shorter.
-      const bool split = P2 || (!UNPK && d0 >= split_d0);  // (UNPK: the first loop ends where the split steps begin)
+      const bool split = P2 || (!BYKIND && d0 >= split_d0);  // (BYKIND: the split steps are the last loop)
       // helper lanes mirror a main lane 64 away: NG = 128: wave 1 -> wave 0; NG = 256: wave 0 -> wave 1, wave 3 -> wave 2
       const bool narrow = NARROW && d0 >= narrow_d0;
       if (NARROW && d0 == narrow_d0) {
@@ -1776,10 +1782,10 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
           if (k < sweep_rows) sf_trail_load<NQ>(X.cg, W, tid & 63, T.row - k, dc[k]);
       }
       if (__ballot(valid)) {
-        if (!P2 && d0 < 8) sf_fast_cell<true, WT, SF_SEC_ALL, false, FOLD, 1>(X, d, i, valid, slot2, slotd, H, HU, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
-        else if (!P2 && d0 < SF_FAST_TINY_D0) sf_fast_cell<true, WT, SF_SEC_ALL, false, FOLD, 5>(X, d, i, valid, slot2, slotd, H, HU, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
-        else if (!P2 && d0 < SF_FAST_CHUNK_D0) sf_fast_cell<false, WT, SF_SEC_ALL, true, FOLD, SFD_MAXLOOP, TBLK>(X, d, i, valid, slot2, slotd, H, HU, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
-        else if (!P2 && !split) sf_fast_cell<false, WT, SF_SEC_ALL, false, FOLD, SFD_MAXLOOP, TBLK>(X, d, i, valid, slot2, slotd, H, HU, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
+        if (DO_G && d0 < 8) sf_fast_cell<true, WT, SF_SEC_ALL, false, FOLD, 1>(X, d, i, valid, slot2, slotd, H, HU, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
+        else if (DO_G && d0 < SF_FAST_TINY_D0) sf_fast_cell<true, WT, SF_SEC_ALL, false, FOLD, 5>(X, d, i, valid, slot2, slotd, H, HU, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
+        else if (DO_CH && d0 < SF_FAST_CHUNK_D0) sf_fast_cell<false, WT, SF_SEC_ALL, true, FOLD, SFD_MAXLOOP, TBLK>(X, d, i, valid, slot2, slotd, H, HU, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
+        else if (!P2 && !split) sf_fast_cell<false, WT, SF_SEC_ALL, false, FOLD, SFD_MAXLOOP, TBLK, false, UNPK && PH == 1>(X, d, i, valid, slot2, slotd, H, HU, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
         else if (DML4 && narrow) {
           // terms m = 4 .. d-5: main [4, cA), wave 2 [cA, cB), wave 3 [cB, d-5]
           const int nmain = dml_terms / 5, cA = SFD_TURN + 1 + nmain, cB = cA + (dml_terms - nmain + 1) / 2;
@@ -1799,7 +1805,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
           if (SHARE) sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_DML | SF_SEC_PRE, false, FOLD, SFD_MAXLOOP, TBLK>(X, d, i, valid, slot2, slotd, H, HU, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub, SFD_TURN + 1, dml_cut - 1);
           else if (DML2) {
             dec = sf_fast_dml2<WT>(X, d, tid & 63, i, valid);
-            sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_PRE, false, FOLD, SFD_MAXLOOP, TBLK, false, P2>(X, d, i, valid, slot2, slotd, H, HU, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
+            sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_PRE, false, FOLD, SFD_MAXLOOP, TBLK, false, UNPK && P2>(X, d, i, valid, slot2, slotd, H, HU, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
           } else sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_DML | SF_SEC_PRE, false, FOLD, SFD_MAXLOOP, TBLK>(X, d, i, valid, slot2, slotd, H, HU, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
         } else if (MERGE) {
           // Merged helper (W <= 128).  ONE helper wave serves both diagonals of the step: it works on the list of the
@@ -1889,12 +1895,23 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
     };
     {
       int d0 = SFD_TURN + 1;
-      const int d_unp = UNPK ? split_d0 : W;
-      for (; d0 < d_unp && d0 < W; d0 += 2) step(d0, std::false_type{});
-      if constexpr (UNPK) {
+      // BYKIND: the steps of a fold as four loops, one per kind of step — d0 < 12 (size-tested code), 12 <= d0 < 36 (guarded code),
+      // the unsplit steps from d0 = 36 on, the split steps — instead of one loop with the kinds as branches: the same code, but every
+      // loop gets its own register allocation and schedule (W = 120, per 262 144 folds: one loop 59.0 ms; two loops, the split steps
+      // apart, 59.8 packed / 57.5 with the split steps' state unpacked; three loops 56.6; four 56.2).
+      // UNPK: the state is unpacked at d0 = 36 — the first diagonal pair on which every loop size exists (the guarded code before it
+      // needs the saturating packed adds; unpacked with v_add_i16 clamp it measured slower: 58.8 ms).
+      if constexpr (BYKIND) {
+        for (; d0 < SF_FAST_TINY_D0 && d0 < W; d0 += 2) step(d0, std::integral_constant<int, 3>{});
+        for (; d0 < SF_FAST_CHUNK_D0 && d0 < W; d0 += 2) step(d0, std::integral_constant<int, 4>{});
+        if constexpr (UNPK) {
 #pragma unroll
-        for (int x = 0; x < 27; x++) HU.v[x] = (short)((x & 1) ? (H[x >> 1] >> 16) : (H[x >> 1] & 0xffffu));
-        for (; d0 < W; d0 += 2) step(d0, std::true_type{});
+          for (int x = 0; x < 27; x++) HU.v[x] = (short)((x & 1) ? (H[x >> 1] >> 16) : (H[x >> 1] & 0xffffu));
+        }
+        for (; d0 < split_d0 && d0 < W; d0 += 2) step(d0, std::integral_constant<int, 1>{});
+        for (; d0 < W; d0 += 2) step(d0, std::integral_constant<int, 2>{});
+      } else {
+        for (; d0 < W; d0 += 2) step(d0, std::integral_constant<int, 0>{});
       }
     }
 

@@ -42,6 +42,11 @@ STAMP_PATCHES = [
     (FAST, "      slot2 += 2; if (slot2 >= SF_FAST_NR) slot2 -= SF_FAST_NR;\n      slotd += 2; if (slotd >= SF_FAST_NR) slotd -= SF_FAST_NR;\n    };",
      "      if (SFL) { atomicAdd(SFP + 3, (unsigned long long)(clock64() - SFT0)); atomicAdd(SFP + 4, 1ull); }\n"
      "      slot2 += 2; if (slot2 >= SF_FAST_NR) slot2 -= SF_FAST_NR;\n      slotd += 2; if (slotd >= SF_FAST_NR) slotd -= SF_FAST_NR;\n    };"),
+    (FAST, "      if (__ballot(valid)) {\n        if (!P2 && d0 < 8)",
+     "      if (SFL) atomicAdd(SFP + 6, (unsigned long long)(clock64() - SFT0));\n      if (__ballot(valid)) {\n        if (!P2 && d0 < 8)"),
+    (FAST, "            dec = sf_fast_dml2<WT>(X, d, tid & 63, i, valid);\n",
+     "            dec = sf_fast_dml2<WT>(X, d, tid & 63, i, valid);\n            SF_PIN(dec);\n"
+     "            if (SFL) atomicAdd(SFP + 7, (unsigned long long)(clock64() - SFT0));\n"),
     (HOST, "    int rc = ensure(g.status, sizeof(int));\n    if (rc) return rc;\n    HIPCHK(hipMemset(g.status.p, 0, sizeof(int)));",
      "    int rc = ensure(g.status, 65536);\n    if (rc) return rc;\n    HIPCHK(hipMemset(g.status.p, 0, 65536));"),
     (HOST, "  ProfPair::prof_drain();\n  if (ms) *ms = g.prof_ms;",
@@ -61,6 +66,7 @@ VARIANTS = {
     "nb6": ([(FAST, "#define SF_HELP_NB_128 4", "#define SF_HELP_NB_128 6")], []),
     "nb8": ([(FAST, "#define SF_HELP_NB_128 4", "#define SF_HELP_NB_128 8")], []),
     "nb2": ([(FAST, "#define SF_HELP_NB_128 4", "#define SF_HELP_NB_128 2")], []),
+    "unpall128": ([(FAST, "constexpr bool UNPK = SF_FAST_UNPACK && (NG == 128) && (WT == 120) && SF_FAST_DML2;", "constexpr bool UNPK = SF_FAST_UNPACK && (NG == 128) && SF_FAST_DML2;")], []),
     "pb4": ([], ["-DSF_UNP_PB=4"]),
     # artificial skew between the two diagonal groups of a workgroup (the odd group starts its step later)
     "skew4": ([(FAST, "      constexpr bool P2 = decltype(p2_tag)::value;\n      const int d = d0 + grp;\n", "      constexpr bool P2 = decltype(p2_tag)::value;\n      const int d = d0 + grp;\n      if (grp == 1) __builtin_amdgcn_s_sleep(4);\n")], []),

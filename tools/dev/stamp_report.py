@@ -30,8 +30,13 @@ for st in range(64):
     endbar = t_eb[0] - t_fin[0]
     fix = t_end[0] - t_eb[0]
     waits = [(t_ex[k] - pre[k]) if split else (t_eb[k] - t_fin[k]) for k in range(4)]
-    print("%4d | %7.0f %7.0f %7.0f %7.0f | %7.0f %7.0f %7.0f %7.0f | %7.0f   %6.0f %6.0f %6.0f %6.0f"
-          % (d0, pre[0], pre[1], pre[2], pre[3], exch, fin, endbar, fix, t_end[0], waits[0], waits[1], waits[2], waits[3]))
+    extra = ""
+    if w[0][6]:
+        ta = w[0][6] / n[0]
+        tb = w[0][7] / n[0] if w[0][7] else ta
+        extra = "   w0: control %5.0f, dml2 %5.0f, cell %5.0f" % (ta, tb - ta, pre[0] - tb)
+    print("%4d | %7.0f %7.0f %7.0f %7.0f | %7.0f %7.0f %7.0f %7.0f | %7.0f   %6.0f %6.0f %6.0f %6.0f%s"
+          % (d0, pre[0], pre[1], pre[2], pre[3], exch, fin, endbar, fix, t_end[0], waits[0], waits[1], waits[2], waits[3], extra))
     tot["pre"] += max(pre); tot["exch"] += exch; tot["fin"] += fin; tot["endbar"] += endbar; tot["fix"] += fix; tot["step"] += t_end[0]
 print("sum over steps (wave 0's clock): step %.0f; longest pre-barrier work %.0f, exchange-barrier wait of wave 0 %.0f, finish %.0f, "
       "end-barrier wait %.0f, fix-up %.0f" % (tot["step"], tot["pre"], tot["exch"], tot["fin"], tot["endbar"], tot["fix"]))

@@ -1533,7 +1533,9 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
   X.D = D; X.F = F; X.R = Rows; X.W = W; X.fold = FOLD; X.maxd = D->max_pair_dist;
   constexpr bool MERGE = MG && SF_HELP_MERGE && (NG == 128);
   // the split steps' generic-loop recurrence with its state unpacked (SfHU): the W = 120 instantiation
-  constexpr bool UNPK = SF_FAST_UNPACK && (NG == 128) && (WT == 120) && SF_FAST_DML2;
+  // (every narrow instantiation: +2-3 % at W = 64 .. 117 on top of the loops by kind, W = 128 +-0; the wide kernel measured 0.5-1.5 %
+  // SLOWER with it — W = 200: 55.1 -> 55.6 ms per 65 536 folds, the generic wide instantiation at W = 136 .. 250 — and stays packed)
+  constexpr bool UNPK = SF_FAST_UNPACK && (NG == 128) && SF_FAST_DML2;
   constexpr bool BYKIND = SF_LOOPS_BY_KIND != 0;  // the steps of a fold as one loop per kind of step (see the loops)
   // rolling-row offsets from SfFastRows (see sf_fast_cell): 1 = yes, 2 = yes + the long read batches of the generic merged-helper
   // instantiation, 0 = no (the generic wide kernel)

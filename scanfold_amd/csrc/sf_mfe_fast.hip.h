@@ -1073,12 +1073,13 @@ __device__ __forceinline__ uint32_t sf_wave_next(uint32_t v) {
 // mind a term twice), and a butterfly over the chunks joins them.  Batches of eight terms starting at even m with the address
 // arithmetic of the one-cell loop (two alternating steps + compile-time offsets, here per lane).  d odd: the term m = d-5
 // (even, so that the batches can stop at an odd m) is done by every chunk on its own.
-template <int WT>
+// LGC: the chunk width as a compile-time constant (the caller runs the steps of each width as a loop of their own), 0 = from d
+template <int WT, int LGC = 0>
 __device__ __forceinline__ int sf_fast_dml2(const SfFastCtx &X, const int d, const int lane, const int i_own, const bool valid) {
   constexpr bool FOLD = false;
   const int W = WT ? WT : X.W;
   const int n = W - d, npairs = (n + 1) >> 1;
-  const int lg = npairs <= 7 ? 3 : (npairs <= 15 ? 4 : 5);  // lanes per chunk = 1 << lg (pairs + at least one feeder lane)
+  const int lg = LGC ? LGC : (npairs <= 7 ? 3 : (npairs <= 15 ? 4 : 5));  // lanes per chunk = 1 << lg (pairs + at least one feeder lane)
   const int NC = 64 >> lg;
   const int q = lane & ((1 << lg) - 1), c = lane >> lg;
   const int elast = (d & 1) ? d - 6 : d - 5;            // last term of the batched range (odd)
@@ -1537,6 +1538,10 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
   // SLOWER with it — W = 200: 55.1 -> 55.6 ms per 65 536 folds, the generic wide instantiation at W = 136 .. 250 — and stays packed)
   constexpr bool UNPK = SF_FAST_UNPACK && (NG == 128) && SF_FAST_DML2;
   constexpr bool BYKIND = SF_LOOPS_BY_KIND != 0;  // the steps of a fold as one loop per kind of step (see the loops)
+  // ... and the split steps of the merged-helper instantiations once more by the chunk width of their two-cells-per-lane multiloop
+  // split, the width a compile-time constant in each (W = 120: 56.2 -> 55.4 ms per 262 144 folds, W = 100 +1.4 %; the instantiation
+  // without the merged helper, W = 118 .. 128, measured 1.2 % slower with it)
+  constexpr bool LGLOOPS = BYKIND && MG && (NG == 128) && SF_FAST_DML2;
   // rolling-row offsets from SfFastRows (see sf_fast_cell): 1 = yes, 2 = yes + the long read batches of the generic merged-helper
   // instantiation, 0 = no (the generic wide kernel)
   constexpr int TBLK = WT > 0 ? 1 : (NG == 128 ? (MG ? 2 : 1) : 0);
@@ -1716,9 +1721,12 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
     SfHU HU;
     auto step = [&](const int d0, auto phase_tag) {
       // PH: the kind of step this instantiation of the body is for (BYKIND: one loop per kind, see below) — 3: d0 < 12 (size-tested
-      // code), 4: 12 <= d0 < 36 (guarded code), 1: the unsplit steps from d0 = 36 on, 2: the split steps; 0: any (one loop)
+      // code), 4: 12 <= d0 < 36 (guarded code), 1: the unsplit steps from d0 = 36 on, 2: the split steps, 5: the wide kernel's split
+      // steps from the diagonal on where a diagonal's cells fit one wave (NARROW); 0: any (one loop)
       constexpr int PH = decltype(phase_tag)::value;
-      constexpr bool P2 = (PH == 2);
+      constexpr bool P2 = (PH == 2 || PH >= 5);  // a split step (5: the wide kernel's NARROW phase, 6 / 7: the narrow kernel's split steps
+                                                 // whose two-cells-per-lane multiloop split runs in chunks of 16 / 8 lanes — loops of their own as well)
+      constexpr int LGC = PH == 6 ? 4 : (PH == 7 ? 3 : (PH == 2 && LGLOOPS ? 5 : 0));
       constexpr bool DO_G = (PH == 0 || PH == 3), DO_CH = (PH == 0 || PH == 4);
       const int d = d0 + grp;
       if (d0 == SFD_TURN + 1 + 2 && tid == 0) *next_slot = fetched;            // the barriers of this step publish it
@@ -1730,7 +1738,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
       // then the first wave finishes the cell.  The dependent chain of such a step is ~45 % shorter.
       const bool split = P2 || (!BYKIND && d0 >= split_d0);  // (BYKIND: the split steps are the last loop)
       // helper lanes mirror a main lane 64 away: NG = 128: wave 1 -> wave 0; NG = 256: wave 0 -> wave 1, wave 3 -> wave 2
-      const bool narrow = NARROW && d0 >= narrow_d0;
+      const bool narrow = NARROW && (PH == 5 || (PH == 0 && d0 >= narrow_d0));
       if (NARROW && d0 == narrow_d0) {
         // the one-time move of the centres' state: old owners tg = 96..159 -> new owners tg - 32 = 64..127
         uint32_t *const xa = (uint32_t *)X.BN;  // dword = cell of the interleaved ring; row r, cell 100 + lane
@@ -1806,7 +1814,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
         else if (!helper) {
           if (SHARE) sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_DML | SF_SEC_PRE, false, FOLD, SFD_MAXLOOP, TBLK>(X, d, i, valid, slot2, slotd, H, HU, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub, SFD_TURN + 1, dml_cut - 1);
           else if (DML2) {
-            dec = sf_fast_dml2<WT>(X, d, tid & 63, i, valid);
+            dec = sf_fast_dml2<WT, LGC>(X, d, tid & 63, i, valid);
             sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_PRE, false, FOLD, SFD_MAXLOOP, TBLK, false, UNPK && P2>(X, d, i, valid, slot2, slotd, H, HU, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
           } else sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_DML | SF_SEC_PRE, false, FOLD, SFD_MAXLOOP, TBLK>(X, d, i, valid, slot2, slotd, H, HU, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);
         } else if (MERGE) {
@@ -1911,7 +1919,15 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
           for (int x = 0; x < 27; x++) HU.v[x] = (short)((x & 1) ? (H[x >> 1] >> 16) : (H[x >> 1] & 0xffffu));
         }
         for (; d0 < split_d0 && d0 < W; d0 += 2) step(d0, std::integral_constant<int, 1>{});
-        for (; d0 < W; d0 += 2) step(d0, std::integral_constant<int, 2>{});
+        if constexpr (LGLOOPS) {
+          // (chunks of 32 lanes while a diagonal has more than 30 cells, 16 down to 15 cells, then 8: d0 >= W - 30 / W - 14)
+          for (; d0 < W - 30 && d0 < W; d0 += 2) step(d0, std::integral_constant<int, 2>{});
+          for (; d0 < W - 14 && d0 < W; d0 += 2) step(d0, std::integral_constant<int, 6>{});
+          for (; d0 < W; d0 += 2) step(d0, std::integral_constant<int, 7>{});
+        }
+        for (; d0 < (NARROW ? narrow_d0 : W) && d0 < W; d0 += 2) step(d0, std::integral_constant<int, 2>{});
+        if constexpr (NARROW)
+          for (; d0 < W; d0 += 2) step(d0, std::integral_constant<int, 5>{});
       } else {
         for (; d0 < W; d0 += 2) step(d0, std::integral_constant<int, 0>{});
       }

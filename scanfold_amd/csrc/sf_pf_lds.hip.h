@@ -33,7 +33,6 @@
 //         weight rows are wave-uniform and come from per-column lane tables (v_readlane).
 // FP64 throughout; sums are re-associated with respect to the oracle (agreement ~1e-12 relative).
 #pragma once
-#include <type_traits>
 #include "sf_energy.h"
 #include "sf_pf.hip.h"
 
@@ -278,11 +277,11 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
       }
       __syncthreads();
     }
-    // One column of the inside pass for one team (TM, compile time).  Every team runs its OWN copy of the column loop (the
-    // barriers of the copies pair up: s_barrier counts arrivals, not places) — the roles are wave-uniform, and a loop per role
-    // gets its own register allocation: team 0's 27 FP64 recurrence registers are live in team 0's loop only.
-    auto inside_col = [&](const int j, auto team_tag) {
-      constexpr int TM = decltype(team_tag)::value;
+    // (Round 5, after the MFE kernels gained 5-8 % from running each KIND of step as a loop of its own: the same idea here — every
+    // team its own copy of the column loops, roles as compile-time constants, team 0's 27 recurrence registers live in its loop
+    // only — is bit-identical, compiles to 197 instead of 217 VGPRs, and changes nothing that matters: the cfg3 scan's partition
+    // functions 65.4 -> 67.6 ms (W = 120 instantiation), 53.5 -> 51.3 ms at W = 100.  Neither version spills; not kept.)
+    for (int j = resume ? W - step + 1 : SFD_TURN + 2; j <= W + 1; j++) {
       // j = W+1 only finishes qm of column W
       const int s = (j <= c - 1) ? c : c + SF_PFL_SLOTS;
       const int i = s - j, d = j - i;
@@ -330,7 +329,7 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
         return m + m2;
       };
       double wml = 0.0;      // team 2: multiloop-stem weight of (i,j), fetched from device memory ahead of its use after the barrier
-      if constexpr (TM == 0) {
+      if (team == 0) {
         if (valid) {
           const int type = OWN(i, j);
           const int si1 = S[i + 1], sj1 = S[j - 1];
@@ -390,7 +389,7 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
           ZP[i] = z;
         }
         if (qvalid) ZP[5 * VW + i] = qm_part(1);
-      } else if constexpr (TM == 1) {
+      } else if (team == 1) {
         if (valid) {
           const int type = OWN(i, j);
           const int sp = S[i + 1];  // row of the u1 = 0 bulge candidates
@@ -410,7 +409,7 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
           ZP[VW + i] = (gb + gb2) * (type > 2 ? xTAU : 1.0);
         }
         if (qvalid) ZP[4 * VW + i] = qm_part(0);
-      } else if constexpr (TM == 2) {
+      } else if (team == 2) {
         if (valid) {
           const int type = OWN(i, j);
           if (type) wml = sfx_mlstem(X, type, (i > 1 || nbL) ? S[i - 1] : -1, (j < W || nbR) ? S[j + 1] : -1);
@@ -464,8 +463,8 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
         }
       }
       __syncthreads();
-      if (TM == 2 && qvalid) QMD(dq, i) = ZP[5 * VW + i] + ZP[4 * VW + i];
-      if (TM == 2 && valid) {
+      if (team == 2 && qvalid) QMD(dq, i) = ZP[5 * VW + i] + ZP[4 * VW + i];
+      if (team == 2 && valid) {
         const int type = OWN(i, j);
         const int tr = sfd_rtype(type);
         const double qbij = type ? (ZP[i] + ZP[VW + i]) + (ZP[2 * VW + i] + ZP[3 * VW + i]) : 0.0;
@@ -479,22 +478,6 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
         qm1c[i] = m1;
       }
       __syncthreads();
-    };
-    {
-      const int jfirst = resume ? W - step + 1 : SFD_TURN + 2;
-      if (team == 0) {
-        for (int j = jfirst; j <= W + 1; j++) inside_col(j, std::integral_constant<int, 0>{});
-        if (keep) {  // team 0's recurrence registers for the next window of the run (the rest of the state: below)
-#pragma unroll
-          for (int u = 0; u < 27; u++) sv[SV_H + c * 27 + u] = H[u];
-        }
-      } else if (team == 1) {
-        for (int j = jfirst; j <= W + 1; j++) inside_col(j, std::integral_constant<int, 1>{});
-      } else if (team == 2) {
-        for (int j = jfirst; j <= W + 1; j++) inside_col(j, std::integral_constant<int, 2>{});
-      } else {
-        for (int j = jfirst; j <= W + 1; j++) inside_col(j, std::integral_constant<int, 3>{});
-      }
     }
 
     if (keep) {  // the inside state for the next window of the run (nothing below reads sv)
@@ -502,6 +485,10 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
       for (int x = tid; x < NC; x += SF_PFL_NT) sv[x] = QB[x];
       for (int x = SV_DER + tid; x < 2 * NC + 12 * RP + 2 * VW + 8; x += SF_PFL_NT)
         sv[x] = x < SV_QM1 ? DER[x - SV_DER] : QM1[x - SV_QM1];
+      if (team == 0) {
+#pragma unroll
+        for (int u = 0; u < 27; u++) sv[SV_H + c * 27 + u] = H[u];
+      }
     }
     // ================= exterior =================
     // q5[j] = q5[j-1] + sum_i q5[i-1] qb[i,j] ExtLoop(i,j) and its mirror image q3, each by ONE wave as a sweep
@@ -596,14 +583,15 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
     __syncthreads();
 
     // ================= outside: columns l descending =================
+#pragma unroll
+    for (int u = 0; u < 27; u++) H[u] = 0.0;
     double mbd = 0.0, cd = 0.0;
-    auto outside_col = [&](const int l, auto team_tag) {  // (one column for one team: see inside_col)
-      constexpr int TM = decltype(team_tag)::value;
+    for (int l = W; l >= SFD_TURN + 2; l--) {
       const int s = (l <= c - 1) ? c : c + SF_PFL_SLOTS;
       const int k = s - l, d = l - k;
       const bool valid = (k >= 1) && (d >= SFD_TURN + 1);
       const bool inner = (k > 1) && (l < W);
-      const double qbkl = (valid && TM != 0) ? QBC(k, l) : 0.0;  // qb[k,l]: replaced by ob[k,l] at the end of this column
+      const double qbkl = (valid && team != 0) ? QBC(k, l) : 0.0;  // qb[k,l]: replaced by ob[k,l] at the end of this column
       const double *R1c = RV + (2 + (l & 1)) * VW, *R01c = RV + (4 + (l & 1)) * VW, *R0c = RV + (l & 1) * VW;
       double *R0n = RV + ((l & 1) ^ 1) * VW, *R1n = RV + (2 + ((l & 1) ^ 1)) * VW, *R01n = RV + (4 + ((l & 1) ^ 1)) * VW;
       // lane tables, entry L: column min(l+L, W)
@@ -643,7 +631,7 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
         for (; m <= mhi; m++) r1 += QBC(k, m) * fW[SF_PK_ROW(BWD[m])] * QMD(m - 1 - l, l);
         return r1 + r1b;
       };
-      if constexpr (TM == 0) {
+      if (team == 0) {
         if (valid) {
           const double *dI3 = DERP(0, l + 3) + k;
           const int kr3 = r3 ? k - 3 : 1;  // row for speculative reads
@@ -713,7 +701,7 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
           if (!type) o = 0.0;
           ZP[k] = o;
         }
-      } else if constexpr (TM == 1) {
+      } else if (team == 1) {
         if (valid) {
           const int type = OWN(k, l);
           const int sp1 = S[k - 1];
@@ -732,7 +720,7 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
           ZP[VW + k] = (gb + gb2) * (type > 2 ? xTAU : 1.0);  // rtype(type) > 2 <=> type > 2
           ZP[4 * VW + k] = r1_part(0);
         }
-      } else if constexpr (TM == 2) {
+      } else if (team == 2) {
         if (valid) {
           const int type = OWN(k, l);
           const int rt = sfd_rtype(type);
@@ -794,17 +782,17 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
       // The column's results, shared out: team 2 writes the tables the next column's loops read, team 1 the multiloop vectors,
       // team 3 the pair probability and what hangs on it (each forms the cell's sum from the partial sums itself; qb[k,l],
       // which team 2 overwrites here, was read before the barrier).
-      if (TM != 0 && valid) {
+      if (team != 0 && valid) {
         const int type = OWN(k, l);
         double o = 0.0;
         if (type && qbkl != 0.0) o = inner ? (ZP[k] + ZP[VW + k]) + (ZP[2 * VW + k] + ZP[3 * VW + k]) : ZP[k];
         const int fa = SF_PK_ROW(BWD[l]) + SF_PK_CODE(FWD[k]);  // (S[l], S[l-1]) x (S[k], S[k+1]): LDS, not device memory
-        if constexpr (TM == 2) {
+        if (team == 2) {
           QBC(k, l) = o;
           DERP(0, l)[k] = type ? o * FAC[fa] : 0.0;
           DERP(1, l)[k] = type ? o * FAC[625 + fa] : 0.0;
           DERP(2, l)[k] = (type > 2) ? o * xTAU : o;
-        } else if constexpr (TM == 1) {
+        } else if (team == 1) {
           const double w = type ? o * FAC[1250 + fa] : 0.0;
           const double r0 = w + xMLbase * R0c[k];
           const double r1 = (ZP[5 * VW + k] + ZP[6 * VW + k]) + ZP[4 * VW + k];
@@ -821,17 +809,6 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
         }
       }
       __syncthreads();
-    };
-    if (team == 0) {
-#pragma unroll
-      for (int u = 0; u < 27; u++) H[u] = 0.0;
-      for (int l = W; l >= SFD_TURN + 2; l--) outside_col(l, std::integral_constant<int, 0>{});
-    } else if (team == 1) {
-      for (int l = W; l >= SFD_TURN + 2; l--) outside_col(l, std::integral_constant<int, 1>{});
-    } else if (team == 2) {
-      for (int l = W; l >= SFD_TURN + 2; l--) outside_col(l, std::integral_constant<int, 2>{});
-    } else {
-      for (int l = W; l >= SFD_TURN + 2; l--) outside_col(l, std::integral_constant<int, 3>{});
     }
     mbd = sf_block_sum(mbd, red);
     __syncthreads();

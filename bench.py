@@ -47,7 +47,7 @@ WORKLOADS = {
     # BASELINE.json configs[4] on the GPUs given (`--config cfg5`; one step is ~36 s on one MI355X)
     "cfg5": dict(name="cfg5: 30 kb synthetic RNA, W=200, step=1, 1000 di-shuffles + partition function", L=30000, seed=3,
                  W=200, step=1, r=1000, shuffle="di", shuffle_seed=2026,
-                 metric="windows/sec (W=200, step=1, 1000 shuffles, partition function)", verify=4,
+                 metric="windows/sec (W=200, step=1, 1000 shuffles, partition function)", verify=32, verify_engine="twin",
                  counters="profiles/r04/cfg5_mfe_counters.json"),
 }
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
@@ -332,10 +332,12 @@ def verify_indices(n_loc, n_check):
     return np.unique(np.linspace(0, n_loc - 1, n_check).astype(np.int64))
 
 
-def verify_sample(seq, W, step, r, kind, seed, lo, n_loc, en, db, cen, div, n_check=64, paramset=None):
+def verify_sample(seq, W, step, r, kind, seed, lo, n_loc, en, db, cen, div, n_check=64, paramset=None, engine="checker"):
     """Compare n_check windows of the LAST timed step (device tensors of rank 0's shard) with the oracle: every one
     of the r+1 energies on the oracle's own shuffles, structure, centroid, ensemble diversity.  Returns
-    (windows checked, mismatching windows)."""
+    (windows checked, mismatching windows).  engine: "checker" = oracle/sf_oracle.c (O(n^4) outside pass: seconds per 200-mer
+    window with 1001 folds), "twin" = oracle/sf_cpu_twin.c, the fast CPU engine that tests/test_oracle.py holds equal to the
+    checker — what cfg5's 32 windows x 1001 folds of 200-mers are checked with."""
     import numpy as np
     from oracle import oracle
     from scanfold_amd import params
@@ -349,7 +351,11 @@ def verify_sample(seq, W, step, r, kind, seed, lo, n_loc, en, db, cen, div, n_ch
     cen_dev = cen[idx].cpu().numpy()
     div_dev = div[idx].cpu().numpy()
     rows = np.concatenate([oracle.shuffle_windows(seq, W, step, lo + int(w), 1, r, kind, seed) for w in idx])
-    ref = oracle.scan_windows(np.frombuffer(b"NACGU", dtype=np.uint8)[rows], len(idx), r)
+    ascii_rows = np.frombuffer(b"NACGU", dtype=np.uint8)[rows]
+    if engine == "twin" and oracle.twin_available():
+        ref = oracle.twin_scan_windows(ascii_rows, len(idx), r)
+    else:
+        ref = oracle.scan_windows(ascii_rows, len(idx), r)
     bad = 0
     for k in range(len(idx)):
         ok = (ref["energies"][k] == e_dev[k]).all() and ref["structure"][k] == bytes(db_dev[k, :W]).decode() \
@@ -551,14 +557,15 @@ def main():
             v_en, v_db = torch.from_numpy(merged["energies"]), torch.from_numpy(merged["structure"])
             v_cen, v_div = torch.from_numpy(merged["centroid"]), torch.from_numpy(merged["ens_div"])
             checked, bad = verify_sample(seq, W, step, r, kind, wl["shuffle_seed"], 0, n_win, v_en, v_db, v_cen, v_div,
-                                         wl["verify"])
+                                         wl["verify"], engine=wl.get("verify_engine", "checker"))
             picked = verify_indices(n_win, wl["verify"])
             gather_check["verified_windows_per_shard"] = [int(((picked >= a) & (picked < b)).sum())
                                                           for a, b in gather_check["shard_ranges"]]
             if not same:
                 bad += 1
         else:
-            checked, bad = verify_sample(seq, W, step, r, kind, wl["shuffle_seed"], lo, n_loc, en, db, cen, div, wl["verify"])
+            checked, bad = verify_sample(seq, W, step, r, kind, wl["shuffle_seed"], lo, n_loc, en, db, cen, div, wl["verify"],
+                                         engine=wl.get("verify_engine", "checker"))
         algorithmic_bytes = folds_per_launch * bytes_per_fold
         out = {
             "metric": wl["metric"],
@@ -584,9 +591,11 @@ def main():
                          "mfe_kernel_share_of_step": (kern_ms * 1e-3) / elapsed},
             "verified_windows": checked, "verified_mismatches": bad, "device_status": dev_status,
             "gather_check": gather_check,
-            "verified_against": "oracle (sf_oracle.c + sf_shuffle_oracle.c): all %d energies, structure, centroid, "
+            "verified_against": "oracle (%s + sf_shuffle_oracle.c): all %d energies, structure, centroid, "
                                 "ensemble diversity of %d windows of the last timed step%s"
-                                % (r + 1, checked, " (taken from the gathered records of all ranks)" if gather_check else ""),
+                                % ("sf_cpu_twin.c, the CPU engine tests/test_oracle.py holds equal to the checker sf_oracle.c,"
+                                   if wl.get("verify_engine") == "twin" else "sf_oracle.c",
+                                   r + 1, checked, " (taken from the gathered records of all ranks)" if gather_check else ""),
             "params": eng.params.source and os.path.basename(eng.params.source),
             "device": eng.device_name(),
         }

@@ -482,6 +482,8 @@ struct SfPub {
   uint32_t a;  // (mismatchI, mismatch1nI) of the reversed pair: what CI and C1N add to c
   uint32_t b;  // (MLstem + TerminalAU + MLintern, ExtLoop + TerminalAU): what fML and the scratch add to c
   int tau;     // TerminalAU of the pair: what CB adds
+  int type;    // the cell's pair type (constraint applied): the finish after the barrier does not look it up again — two
+               // dependent LDS round trips (nucleotides, then the pair table) at the head of a phase every other wave waits for
 };
 // UCAP (G code only): compile-time bound on the loop sizes that can exist — d <= 7: 1, d <= 11: 5 — so that the unrolled
 // size tests above it (a scalar compare + branch each, ~110 of them) disappear from the first four steps of a fold, which
@@ -529,8 +531,8 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
   // CH (short diagonals, 12 <= d < 36, straight-line code with guarded size tables): whole batches of sizes above
   // the wave-uniform limit are skipped — the kernel is close to VALU-bound, work on sizes that cannot exist is not free
   const int um = CH ? d - 2 - (SFD_TURN + 1) : SFD_MAXLOOP;
-  int type = d <= X.maxd ? X.tPair[S[i] * 8 + S[j]] : 0;  // max_bp_span: longer pairs do not exist
-  if (X.hc.c) {
+  int type = (SEC & SF_SEC_POST) ? pub.type : (d <= X.maxd ? X.tPair[S[i] * 8 + S[j]] : 0);  // max_bp_span: longer pairs do not exist
+  if (!(SEC & SF_SEC_POST) && X.hc.c) {
     // hard constraint of the window (fc.hc_add_from_db, ScanFold-Scan.py:405-410): applied where the pair type is made.
     // The pairs enclosed by (i,j) keep their sequence-only types in the candidate look-ups: a pair the constraint
     // forbids has c = "none" and never wins.  A bracket pair of non-complementary bases (type 7) has no row in the int16
@@ -540,6 +542,7 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
   }
   const int si1 = S[i + 1], sj1 = S[j - 1];
 // @section publish_terms
+  if (SEC & SF_SEC_PRE) pub.type = type;
   if ((SEC & SF_SEC_PRE) && type) {
     const int tr = X.tRPair[S[i] * 8 + S[j]];
     const int sp1 = S[i - 1], sq1 = S[j + 1];
@@ -1055,7 +1058,7 @@ __device__ __forceinline__ uint32_t sf_wave_next(uint32_t v) {
 #ifdef SF_EMUL
   return __shfl_down(v, 1);
 #else
-  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, false);  // wave_shl:1
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, true);  // wave_shl:1, bound_ctrl: no "old" value to set up (a v_mov per use)
 #endif
 }
 
@@ -1780,7 +1783,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
       int fpart = SF_FAST_BIG;
       int dec = SF_FAST_BIG, eh = SF_FAST_BIG, e0 = SF_FAST_BIG;
       SfPub pub;
-      pub.a = pub.b = 0; pub.tau = 0;
+      pub.a = pub.b = 0; pub.tau = 0; pub.type = 0;
       // trailing sweep: the rows i >= W-d0+1 are complete (diagonals < d0 are); this step's rows are requested now, used
       // after the wave's own work
       int dc[DROWS][NQ];
@@ -1884,21 +1887,19 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
       // by these ~800 cycles, all four waves of a workgroup issue the same LDS bursts at the same time and every phase of every wave
       // got ~8 % longer — profiles/r05/mfe_step_stamps_lazy_fixup_rejected.txt against mfe_step_stamps_unpacked.txt.)
       if (grp == 0 && valid && !helper && !dmlw) {
+        // (branch-free: the five entries the two cells x = i and x = i - 1 need are read at once — a cell that does not exist reads
+        // a clamped or neighbouring entry and is dropped by a select — one LDS round trip where the two tested cells took two, in a
+        // phase in which every other wave of the workgroup waits)
         const int d1 = d0 + 1;
-        const int fbd = FBASE(d1), fbe = FBASE(d0);
-        int g[2];
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-          const int x = i - h;  // cell (x, x+d1)
-          g[h] = SF_INF16;
-          if (x >= 1 && x + d1 <= W) {
-            const int v2 = sfd_min((int)X.fML[fbd + x - 1], sfd_min(X.fML[fbe + x], X.fML[fbe + x - 1]) + X.MLbase);
-            if (v2 < SF_FAST_OVF) ovf = 1;
-            g[h] = v2 > SF_FAST_THRESH ? SF_INF16 : v2;
-            if (h == 0) X.fML[fbd + x - 1] = (int16_t)g[h];
-          }
-        }
-        fnb = sfd_min(g[0], g[1]) + X.MLbase;
+        const int16_t *pd = X.fML + FBASE(d1), *pe = X.fML + FBASE(d0);
+        const bool ex0 = i + d1 <= W, ex1 = i >= 2;  // cell (i, i + d1) / (i - 1, i + d0) exists
+        const int ia = i - 1, ib = ex1 ? i - 2 : 0;
+        const int p0 = pd[ia], p1 = pd[ib], q0 = pe[i], q1 = pe[ia], q2 = pe[ib];
+        const int v0 = sfd_min(p0, sfd_min(q0, q1) + X.MLbase), v1 = sfd_min(p1, sfd_min(q1, q2) + X.MLbase);
+        if ((ex0 && v0 < SF_FAST_OVF) || (ex1 && v1 < SF_FAST_OVF)) ovf = 1;
+        const int g0 = (ex0 && v0 <= SF_FAST_THRESH) ? v0 : SF_INF16, g1 = (ex1 && v1 <= SF_FAST_THRESH) ? v1 : SF_INF16;
+        if (ex0) X.fML[FBASE(d1) + ia] = (int16_t)g0;
+        fnb = sfd_min(g0, g1) + X.MLbase;
       }
       slot2 += 2; if (slot2 >= SF_FAST_NR) slot2 -= SF_FAST_NR;
       slotd += 2; if (slotd >= SF_FAST_NR) slotd -= SF_FAST_NR;

@@ -36,19 +36,19 @@ WORKLOADS = {
     # scan, record packing, the RCCL gather, the self-check) can run in seconds inside the GPU test suite
     "cfg1": dict(name="cfg1: 1 kb synthetic RNA, W=120, step=40, 10 di-shuffles", L=1000, seed=1, W=120, step=40, r=10,
                  shuffle="di", shuffle_seed=2026, metric="windows/sec (W=120, step=40, 10 shuffles)", verify=23,
-                 counters="profiles/r04/mfe_counters.json"),
+                 counters="profiles/r05/mfe_counters.json"),
     "cfg2": dict(name="cfg2: 10 kb synthetic RNA, W=120, step=10, 30 di-shuffles", L=10000, seed=2, W=120, step=10, r=30,
                  shuffle="di", shuffle_seed=2026, metric="windows/sec (W=120, step=10, 30 shuffles)", verify=64,
-                 counters="profiles/r04/mfe_counters.json"),
+                 counters="profiles/r05/mfe_counters.json"),
     # BASELINE.json configs[2] — the configuration the metric is quoted on; the default
     "cfg3": dict(name="cfg3: 30 kb synthetic RNA, W=120, step=1, 100 di-shuffles", L=30000, seed=3, W=120, step=1, r=100,
                  shuffle="di", shuffle_seed=2026, metric="windows/sec (W=120, step=1, 100 shuffles)", verify=64,
-                 counters="profiles/r04/mfe_counters.json"),
+                 counters="profiles/r05/mfe_counters.json"),
     # BASELINE.json configs[4] on the GPUs given (`--config cfg5`; one step is ~36 s on one MI355X)
     "cfg5": dict(name="cfg5: 30 kb synthetic RNA, W=200, step=1, 1000 di-shuffles + partition function", L=30000, seed=3,
                  W=200, step=1, r=1000, shuffle="di", shuffle_seed=2026,
                  metric="windows/sec (W=200, step=1, 1000 shuffles, partition function)", verify=32, verify_engine="twin",
-                 counters="profiles/r04/cfg5_mfe_counters.json"),
+                 counters="profiles/r05/cfg5_mfe_counters.json"),
 }
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 EXIT_NEED_GPUS = 3
@@ -267,12 +267,12 @@ def live_counters_per_fold(config, shuffle, input_kind, groups, windows=0, timeo
 
 def calibrated_unit_fractions(sec, W, folds_per_launch, launch_ms, eng=None, n_cu=256):
     """How busy the vector ALUs and the LDS were during the timed launch: instructions per fold (SQ counters) x the folds of
-    a launch x the MEASURED cost of an instruction of this kernel's mix at its occupancy (profiles/r04/mfe_issue_rates.json:
+    a launch x the MEASURED cost of an instruction of this kernel's mix at its occupancy (profiles/r05/mfe_issue_rates.json:
     tools/micro/issue_rates.hip, valu_classes.hip; vector mix from the ISA of the hot blocks) / the launch's duration by HIP
     events.  (Rounds 1-3 assumed 4 cycles per vector instruction; the round-3 review held 2 against it.  Measured: the
     packed int16 / min / bit-select instructions are half-rate, 1.8-1.95 ns per wave64 instruction and SIMD, 32-bit adds
     and moves full-rate, 1.05 ns; this kernel's mix averages 1.72 ns.)"""
-    path = os.path.join(ROOT, "profiles", "r04", "mfe_issue_rates.json")
+    path = os.path.join(ROOT, "profiles", "r05", "mfe_issue_rates.json")
     try:
         rates = json.load(open(path))
         name = eng.device_name() if eng is not None else ""
@@ -296,7 +296,7 @@ def calibrated_unit_fractions(sec, W, folds_per_launch, launch_ms, eng=None, n_c
                                "lds_ns_per_inst_per_cu": rates["lds_ns_per_inst_per_cu"], "n_cu": n_cu},
             "definition": "frac = instructions (or LDS index-active units) of one launch per SIMD (per CU) x measured ns per "
                           "instruction at four waves per SIMD / launch duration; 1.0 = that unit issues back to back",
-            "calibration": "profiles/r04/mfe_issue_rates.json"}
+            "calibration": "profiles/r05/mfe_issue_rates.json"}
 
 
 def reference_python_overhead(seq, W, r, windows=6):

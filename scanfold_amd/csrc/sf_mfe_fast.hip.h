@@ -414,6 +414,8 @@ __device__ __forceinline__ void sf_fast_publish_bn(int16_t *w, const int i0, con
 // included — is formed in 32 bits, so that the load is "scalar base + 32-bit vector offset" (global_load saddr).  From
 // F->tab[idx] the compiler builds a 64-bit address per lane (v_mad_u64_u32, v_lshl_add_u64, add / addc with carry: ~5
 // half-rate vector instructions per gather, four gathers per cell pass).
+// (SF_EMUL: plain indexing.  The real address path — wide kernel only — runs under tests/test_gpu_parity.py::
+// test_mfe_energy_parity_both_kernels (widths 129 ... 256) and tools/gpu_wsweep_full.py)
 #ifdef SF_EMUL
 #define SF_GATHER16(F, field, idx) ((int)(F)->field[idx])
 #else
@@ -685,6 +687,9 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
     // The lane's byte offset into a row of the interleaved table, pinned: a row's address is then ONE add of the row's scalar
     // byte offset (the compiler otherwise rebuilds (row + lane) * 4 + table base — three vector instructions — for every row,
     // because the two-word reads have no room for the base in their offset fields).
+    // (SF_EMUL: plain pointer arithmetic, with sf_emul_check_bn_row on every row.  The pinned LDS-address form below runs under
+    // every -m gpu parity test of this kernel: test_mfe_energy_parity_both_kernels (15 widths), test_config2_all_energies_equal_oracle,
+    // test_poisoned_lds_slack_does_not_move_an_energy (12 widths x 5 patterns), and the every-width sweep tools/gpu_wsweep_full.py)
 #ifdef SF_EMUL
     const int bno = 4 * i0;
 #define BNROWB(b) ((const int16_t *)((const char *)X.BN + (bno + (b))))
@@ -1039,6 +1044,8 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
 // @section wave_min
 // minimum over the 64 lanes of a wave, returned in every lane.  DPP row operations + one readlane: no LDS
 // round trips (the generic __shfl_xor butterfly lowers to ds_bpermute, ~6 dependent LDS-crossbar trips).
+// (SF_EMUL: a plain loop over the lanes.  The DPP sequence runs in the trailing sweep of every fold whose structure is not wanted:
+// tests/test_gpu_parity.py::test_mfe_energy_parity_both_kernels, test_config2_all_energies_equal_oracle)
 __device__ __forceinline__ int sf_wave_min(int v) {
 #ifdef SF_EMUL
   return sfemul_wave_min(v);
@@ -1054,6 +1061,7 @@ __device__ __forceinline__ int sf_wave_min(int v) {
 }
 
 // the 32-bit value of the next lane (lane l gets lane l+1's; the last lane's result is unspecified)
+// (SF_EMUL: __shfl_down.  The DPP form runs in sf_fast_dml2 — the split steps of every narrow-kernel fold: the same GPU tests)
 __device__ __forceinline__ uint32_t sf_wave_next(uint32_t v) {
 #ifdef SF_EMUL
   return __shfl_down(v, 1);

@@ -42,6 +42,8 @@
 #define SF_PFL_LDS_LIMIT (160 * 1024)
 // A per-column table of wave-uniform values, one entry per lane, read back with v_readlane (no LDS round trip
 // per use).  The table is filled outside divergent control flow.  The CPU emulation keeps it as a plain array.
+// (SF_EMUL cannot see the hazard the pinned load guards against — stale entries in inactive lanes; the v_readlane path runs under
+// tests/test_gpu_parity.py::test_traceback_and_partition_function_parity, test_scan_step_one_shares_inside_tables and the every-width sweep)
 #ifdef SF_EMUL
 #define SF_LANE_TABLE(name, L, expr) int name[64]; for (int L = 0; L < 64; L++) name[L] = (expr)
 #define SF_LANE_GET(name, idx) name[idx]

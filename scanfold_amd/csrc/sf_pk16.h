@@ -45,6 +45,9 @@ __device__ __forceinline__ void sf_store_fence() { asm volatile("" ::: "memory")
 // crossbar (a generic __shfl_xor lowers to ds_bpermute: an LDS round trip).  gfx950: v_permlane32_swap swaps the upper half of one
 // copy with the lower half of another, so the two copies hold (lo, lo) and (hi, hi); v_permlane16_swap the same for the 16-lane
 // rows; lanes 8 apart inside a row meet by a DPP row rotate.
+// (SF_EMUL: __shfl_xor.  The lane swaps run in sf_fast_dml2 of every narrow-kernel fold on the GPU: tests/test_gpu_parity.py::
+// test_mfe_energy_parity_both_kernels — widths with 2, 4 and 8 chunks per wave —, test_config2_all_energies_equal_oracle,
+// tools/gpu_wsweep_full.py, tools/gpu_cfg3_full_check.py)
 #ifdef SF_EMUL
 static inline uint32_t sf_pkmin_xor32(uint32_t v) { return sf_pkmin(v, (uint32_t)__shfl_xor((int)v, 32)); }
 static inline uint32_t sf_pkmin_xor16(uint32_t v) { return sf_pkmin(v, (uint32_t)__shfl_xor((int)v, 16)); }
@@ -64,7 +67,7 @@ __device__ __forceinline__ uint32_t sf_pkmin_xor8(uint32_t v) {
 #endif
 // An int16 value the optimiser must take as given: keeps chains of SCALAR 16-bit operations (v_min_i16, v_add_u16: full rate on
 // MI355X) from being re-packed into half-rate v_pk_* instructions behind v_perm packs by the SLP vectoriser (sf_mfe_fast.hip.h, UNP)
-#ifdef SF_EMUL
+#ifdef SF_EMUL  // (identity either way: only the optimiser is told nothing)
 static inline short sf_opaque16(short x) { return x; }
 #else
 __device__ __forceinline__ short sf_opaque16(short x) { asm("" : "+v"(x)); return x; }

@@ -14,10 +14,10 @@ from concurrent.futures import ThreadPoolExecutor
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 FAST = "scanfold_amd/csrc/sf_mfe_fast.hip.h"
 
-CELLS = "      if (__ballot(valid)) {\n        if (!P2 && d0 < 8)"
+CELLS = "      if (__ballot(valid)) {\n        if (DO_G && d0 < 8)"
 FIN = "        if (!helper && !dmlw && __ballot(valid)) {"
-DML2 = "            dec = sf_fast_dml2<WT>(X, d, tid & 63, i, valid);"
-MAINCALL = ("            sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_PRE, false, FOLD, SFD_MAXLOOP, TBLK, false, P2>(X, d, i, valid, "
+DML2 = "            dec = sf_fast_dml2<WT, LGC>(X, d, tid & 63, i, valid);"
+MAINCALL = ("            sf_fast_cell<false, WT, SF_SEC_P1 | SF_SEC_C0 | SF_SEC_PRE, false, FOLD, SFD_MAXLOOP, TBLK, false, UNPK && P2>(X, d, i, valid, "
             "slot2, slotd, H, HU, ovf, grp == 0, fnb, fpart, dec, eh, e0, dprev, pub);")
 MGHCALL = "            sf_fast_cell<false, WT, SF_SEC_HELP, false, FOLD, SFD_MAXLOOP, TBLK, true>(Xh, d0 + g, iC,"
 
@@ -42,10 +42,10 @@ STAMP_PATCHES = [
     (FAST, "      slot2 += 2; if (slot2 >= SF_FAST_NR) slot2 -= SF_FAST_NR;\n      slotd += 2; if (slotd >= SF_FAST_NR) slotd -= SF_FAST_NR;\n    };",
      "      if (SFL) { atomicAdd(SFP + 3, (unsigned long long)(clock64() - SFT0)); atomicAdd(SFP + 4, 1ull); }\n"
      "      slot2 += 2; if (slot2 >= SF_FAST_NR) slot2 -= SF_FAST_NR;\n      slotd += 2; if (slotd >= SF_FAST_NR) slotd -= SF_FAST_NR;\n    };"),
-    (FAST, "      if (__ballot(valid)) {\n        if (!P2 && d0 < 8)",
-     "      if (SFL) atomicAdd(SFP + 6, (unsigned long long)(clock64() - SFT0));\n      if (__ballot(valid)) {\n        if (!P2 && d0 < 8)"),
-    (FAST, "            dec = sf_fast_dml2<WT>(X, d, tid & 63, i, valid);\n",
-     "            dec = sf_fast_dml2<WT>(X, d, tid & 63, i, valid);\n            SF_PIN(dec);\n"
+    (FAST, "      if (__ballot(valid)) {\n        if (DO_G && d0 < 8)",
+     "      if (SFL) atomicAdd(SFP + 6, (unsigned long long)(clock64() - SFT0));\n      if (__ballot(valid)) {\n        if (DO_G && d0 < 8)"),
+    (FAST, "            dec = sf_fast_dml2<WT, LGC>(X, d, tid & 63, i, valid);\n",
+     "            dec = sf_fast_dml2<WT, LGC>(X, d, tid & 63, i, valid);\n            SF_PIN(dec);\n"
      "            if (SFL) atomicAdd(SFP + 7, (unsigned long long)(clock64() - SFT0));\n"),
     (HOST, "    int rc = ensure(g.status, sizeof(int));\n    if (rc) return rc;\n    HIPCHK(hipMemset(g.status.p, 0, sizeof(int)));",
      "    int rc = ensure(g.status, 65536);\n    if (rc) return rc;\n    HIPCHK(hipMemset(g.status.p, 0, 65536));"),
@@ -67,16 +67,25 @@ VARIANTS = {
     "nb8": ([(FAST, "#define SF_HELP_NB_128 4", "#define SF_HELP_NB_128 8")], []),
     "nb2": ([(FAST, "#define SF_HELP_NB_128 4", "#define SF_HELP_NB_128 2")], []),
     "unpall128": ([(FAST, "constexpr bool UNPK = SF_FAST_UNPACK && (NG == 128) && (WT == 120) && SF_FAST_DML2;", "constexpr bool UNPK = SF_FAST_UNPACK && (NG == 128) && SF_FAST_DML2;")], []),
+    "gather16": ([(FAST, "  (FOLD ? sf_gather16_at((F), (unsigned)offsetof(SfFastParams, field) + ((unsigned)(idx) << 1)) : (int)(F)->field[idx])", "  (sf_gather16_at((F), (unsigned)offsetof(SfFastParams, field) + ((unsigned)(idx) << 1)))")], []),
     "pb4": ([], ["-DSF_UNP_PB=4"]),
     # artificial skew between the two diagonal groups of a workgroup (the odd group starts its step later)
     "skew4": ([(FAST, "      constexpr bool P2 = decltype(p2_tag)::value;\n      const int d = d0 + grp;\n", "      constexpr bool P2 = decltype(p2_tag)::value;\n      const int d = d0 + grp;\n      if (grp == 1) __builtin_amdgcn_s_sleep(4);\n")], []),
     "skew12": ([(FAST, "      constexpr bool P2 = decltype(p2_tag)::value;\n      const int d = d0 + grp;\n", "      constexpr bool P2 = decltype(p2_tag)::value;\n      const int d = d0 + grp;\n      if (grp == 1) __builtin_amdgcn_s_sleep(12);\n")], []),
     "skew4e": ([(FAST, "      constexpr bool P2 = decltype(p2_tag)::value;\n      const int d = d0 + grp;\n", "      constexpr bool P2 = decltype(p2_tag)::value;\n      const int d = d0 + grp;\n      if (grp == 0) __builtin_amdgcn_s_sleep(4);\n")], []), "pb6": ([], ["-DSF_UNP_PB=6"]), "pb12": ([], ["-DSF_UNP_PB=12"]),
     "nounpack": ([], ["-DSF_FAST_UNPACK=0"]),
+    # sections: instructions per fold of a section = product - ablation, by SQ counters (tools/pmc_cmp.sh; profiles/r05/mfe_section_budget.txt)
+    "secP1": ([(FAST, "  if (SEC & SF_SEC_P1) {\n", "  if (false) {\n")], []),
+    "secHELP": ([(FAST, "  if (SEC & SF_SEC_HELP) {\n", "  eh = SF_FAST_BIG;\n  if (false) {\n")], []),
+    "secBN": ([(FAST, "      int gb = SF_FAST_BIG, g1 = SF_FAST_BIG;\n      if (G) {", "      int gb = SF_FAST_BIG, g1 = SF_FAST_BIG;\n      if (true) {\n      } else if (G) {")], []),
+    "secDML1": ([(FAST, "    dec = SF_FAST_BIG;\n  if (FOLD) {", "    dec = SF_FAST_BIG;\n  if (true) return;\n  if (FOLD) {")], []),
+    "secC0": ([(FAST, "  if (SEC & SF_SEC_C0) {\n", "  if (SEC & SF_SEC_C0) e0 = SF_FAST_BIG;\n  if (false) {\n")], []),
+    "secSWEEP": ([(FAST, "      if (sweep_now && sweep_rows > 0) sf_trail_rows<NQ, DROWS>(T, tid & 63, sweep_rows, dc);", "      (void)0;"),
+                  (FAST, "      const bool sweep_now = defer_on && sweeper && split && T.row > 0;", "      const bool sweep_now = false;")], []),
     # phases: which steps cost what (the other phase keeps its barriers and control code)
-    "nosplitwork": ([(FAST, CELLS, "      if (!split && __ballot(valid)) {\n        if (!P2 && d0 < 8)"),
+    "nosplitwork": ([(FAST, CELLS, "      if (!split && __ballot(valid)) {\n        if (DO_G && d0 < 8)"),
                      (FAST, FIN, "        if (false) {")], []),
-    "nounsplitwork": ([(FAST, CELLS, "      if (split && __ballot(valid)) {\n        if (!P2 && d0 < 8)")], []),
+    "nounsplitwork": ([(FAST, CELLS, "      if (split && __ballot(valid)) {\n        if (DO_G && d0 < 8)")], []),
     # split steps, by role
     "nodml2": ([(FAST, DML2, "            dec = SF_INF16;")], []),
     "nomainp1": ([(FAST, MAINCALL, MAINCALL.replace("SF_SEC_P1 | SF_SEC_C0 | SF_SEC_PRE", "SF_SEC_PRE"))], []),
@@ -88,9 +97,9 @@ VARIANTS = {
                   "  if ((SEC & SF_SEC_POST) && type) {\n    f = c + sf_lo(pub.b);\n    cx = sfd_min(c + sf_hi(pub.b), SF_INF16);\n  } else if ((SEC & SF_SEC_POST) && !type) {\n  } else if (false) {\n    X.CI[rbd] = (int16_t)(c + sf_lo(pub.a));")], []),
     "noscratchS": ([(FAST, "  X.cg[SF_CGIDX(i, j)] = (int16_t)cx;", "  if (!(SEC & SF_SEC_POST)) X.cg[SF_CGIDX(i, j)] = (int16_t)cx;")], []),
     # the phases before the split steps
-    "noG": ([(FAST, CELLS, "      if (d0 >= SF_FAST_TINY_D0 && __ballot(valid)) {\n        if (!P2 && d0 < 8)")], []),
-    "noCH": ([(FAST, CELLS, "      if ((d0 < SF_FAST_TINY_D0 || d0 >= SF_FAST_CHUNK_D0) && __ballot(valid)) {\n        if (!P2 && d0 < 8)")], []),
-    "noU36": ([(FAST, CELLS, "      if ((d0 < SF_FAST_CHUNK_D0 || split) && __ballot(valid)) {\n        if (!P2 && d0 < 8)")], []),
+    "noG": ([(FAST, CELLS, "      if (d0 >= SF_FAST_TINY_D0 && __ballot(valid)) {\n        if (DO_G && d0 < 8)")], []),
+    "noCH": ([(FAST, CELLS, "      if ((d0 < SF_FAST_TINY_D0 || d0 >= SF_FAST_CHUNK_D0) && __ballot(valid)) {\n        if (DO_G && d0 < 8)")], []),
+    "noU36": ([(FAST, CELLS, "      if ((d0 < SF_FAST_CHUNK_D0 || split) && __ballot(valid)) {\n        if (DO_G && d0 < 8)")], []),
 }
 
 

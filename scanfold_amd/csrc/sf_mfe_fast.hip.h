@@ -1893,7 +1893,7 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
       // (Round 5 folded this into the even group's NEXT finish — reads issued before the multiloop split, used after it, no separate
       // phase: bit-exact and 3.5 % SLOWER at every width.  The step stamps say why: with the even group no longer trailing the odd one
       // by these ~800 cycles, all four waves of a workgroup issue the same LDS bursts at the same time and every phase of every wave
-      // got ~8 % longer — profiles/r05/mfe_step_stamps_lazy_fixup_rejected.txt against mfe_step_stamps_unpacked.txt.)
+      // got ~8 % longer — profiles/r05/mfe_step_profile_lazy_fixup_rejected.txt against mfe_step_profile_start_of_round.txt.)
       if (grp == 0 && valid && !helper && !dmlw) {
         // (branch-free: the five entries the two cells x = i and x = i - 1 need are read at once — a cell that does not exist reads
         // a clamped or neighbouring entry and is dropped by a select — one LDS round trip where the two tested cells took two, in a

@@ -27,8 +27,8 @@ HOST = "scanfold_amd/csrc/scanfold_hip.hip"
 # steps), the end of the finish [1], the exit of the end-of-step barrier [2], the end of the step (after the fML fix-up) [3];
 # [4] counts.  The sums live behind the status word; sf_prof_get dumps them to $SF_STAMP_OUT (tools/dev/stamp_report.py reads it).
 STAMP_PATCHES = [
-    (FAST, "      constexpr bool P2 = decltype(p2_tag)::value;\n      const int d = d0 + grp;\n",
-     "      constexpr bool P2 = decltype(p2_tag)::value;\n      const int d = d0 + grp;\n"
+    (FAST, "      constexpr bool DO_G = (PH == 0 || PH == 3), DO_CH = (PH == 0 || PH == 4);\n      const int d = d0 + grp;\n",
+     "      constexpr bool DO_G = (PH == 0 || PH == 3), DO_CH = (PH == 0 || PH == 4);\n      const int d = d0 + grp;\n"
      "      unsigned long long *const SFP = (unsigned long long *)(status + 64) + (size_t)(((d0 >> 1) * 4 + (tid >> 6)) * 8);\n"
      "      const bool SFL = (tid & 63) == 0 && (blockIdx.x & 63) == 5;\n"
      "      const long long SFT0 = SFL ? (long long)clock64() : 0;\n"),
@@ -66,13 +66,12 @@ VARIANTS = {
     "nb6": ([(FAST, "#define SF_HELP_NB_128 4", "#define SF_HELP_NB_128 6")], []),
     "nb8": ([(FAST, "#define SF_HELP_NB_128 4", "#define SF_HELP_NB_128 8")], []),
     "nb2": ([(FAST, "#define SF_HELP_NB_128 4", "#define SF_HELP_NB_128 2")], []),
-    "unpall128": ([(FAST, "constexpr bool UNPK = SF_FAST_UNPACK && (NG == 128) && (WT == 120) && SF_FAST_DML2;", "constexpr bool UNPK = SF_FAST_UNPACK && (NG == 128) && SF_FAST_DML2;")], []),
     "gather16": ([(FAST, "  (FOLD ? sf_gather16_at((F), (unsigned)offsetof(SfFastParams, field) + ((unsigned)(idx) << 1)) : (int)(F)->field[idx])", "  (sf_gather16_at((F), (unsigned)offsetof(SfFastParams, field) + ((unsigned)(idx) << 1)))")], []),
+    "ntload": ([(FAST, "    for (int x = tidf; x < W; x += NT) S[x + 1] = sf_encode_nt(src[x]);", "    for (int x = tidf; x < W; x += NT) S[x + 1] = sf_encode_nt(__builtin_nontemporal_load(&src[x]));")], []),
+    # (the scratch stride: "cgNNNN": ([(FAST, "#define SF_CG_ENTRIES(W) ((W) == 120 ? 7168 :", "#define SF_CG_ENTRIES(W) ((W) == 120 ? NNNN :")], []) —
+    #  round 5 re-swept 6796 .. 8192 with tools/pmc_cmp.sh "WRITE_SIZE": 7168 still writes the least, 0.44 kB per fold against 0.78 .. 3.8)
     "pb4": ([], ["-DSF_UNP_PB=4"]),
-    # artificial skew between the two diagonal groups of a workgroup (the odd group starts its step later)
-    "skew4": ([(FAST, "      constexpr bool P2 = decltype(p2_tag)::value;\n      const int d = d0 + grp;\n", "      constexpr bool P2 = decltype(p2_tag)::value;\n      const int d = d0 + grp;\n      if (grp == 1) __builtin_amdgcn_s_sleep(4);\n")], []),
-    "skew12": ([(FAST, "      constexpr bool P2 = decltype(p2_tag)::value;\n      const int d = d0 + grp;\n", "      constexpr bool P2 = decltype(p2_tag)::value;\n      const int d = d0 + grp;\n      if (grp == 1) __builtin_amdgcn_s_sleep(12);\n")], []),
-    "skew4e": ([(FAST, "      constexpr bool P2 = decltype(p2_tag)::value;\n      const int d = d0 + grp;\n", "      constexpr bool P2 = decltype(p2_tag)::value;\n      const int d = d0 + grp;\n      if (grp == 0) __builtin_amdgcn_s_sleep(4);\n")], []), "pb6": ([], ["-DSF_UNP_PB=6"]), "pb12": ([], ["-DSF_UNP_PB=12"]),
+    "pb6": ([], ["-DSF_UNP_PB=6"]), "pb12": ([], ["-DSF_UNP_PB=12"]),
     "nounpack": ([], ["-DSF_FAST_UNPACK=0"]),
     # sections: instructions per fold of a section = product - ablation, by SQ counters (tools/pmc_cmp.sh; profiles/r05/mfe_section_budget.txt)
     "secP1": ([(FAST, "  if (SEC & SF_SEC_P1) {\n", "  if (false) {\n")], []),

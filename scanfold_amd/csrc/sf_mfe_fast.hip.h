@@ -1648,9 +1648,10 @@ __global__ __launch_bounds__(2 * NG, SF_FAST_WAVES_PER_SIMD) void sf_mfe_fast_ke
     // the per-thread addresses of this prologue are recomputed per fold: hoisted out of the fold loop they live in VGPRs through
     // the whole fold, i.e. in spill slots (13 dwords per lane = 13.6 kB per workgroup of private memory competing with the
     // scratch tables for the L2)
-    // (the generic wide instantiation is the exception: 107 -> 16 spilled registers with the pins, and 1.3-2.5 % SLOWER at
-    // W = 160 / 180 / 250 — it keeps the hoisted addresses)
-    constexpr bool PINF = !(NG == 256 && WT == 0);
+    // (round 4 left the generic wide instantiation out — 107 -> 16 spilled registers with the pins but 1.3-2.5 % slower; with the
+    // loops by kind of round 5 the speed is the same either way (W = 136 .. 250: +-0.3 %) and the pins take its private segment
+    // from 504 to 160 B, its scratch instructions from 232 to 104: every instantiation has them now)
+    constexpr bool PINF = true;
     int tidf = tid;
     if (PINF) SF_PIN(tidf);
     __syncthreads();

@@ -3,8 +3,11 @@
 // Replaces energies(seq_list) -> rna_folder -> RNA.fold(seq) (ScanFold-Scan.py:244-246,253-262;
 // ScanFoldFunctions.py:774-789,805-814): r+1 folds per window whose structures the caller throws away.
 //
-// One workgroup folds one sequence at a time (persistent grid, sequences dealt round-robin); two anti-diagonals
-// per step (two thread groups), one barrier per step (two on the long diagonals).  Thread mapping: a thread owns a CENTRE s = i+j (two centres, one per parity of d):
+// One workgroup folds one sequence at a time (persistent grid; a workgroup's first fold is its block index, every further one comes
+// from a device-wide counter); two anti-diagonals per step (two thread groups), one barrier per step (two on the long diagonals).
+// The steps of a fold run as one loop PER KIND of step — size-tested / guarded / unsplit / split (and finer: SF_LOOPS_BY_KIND, the
+// loops at the end of the kernel) — because each loop then gets its own register allocation and schedule: +5-8 % at every width.
+// Thread mapping: a thread owns a CENTRE s = i+j (two centres, one per parity of d):
 // on diagonal d it handles the cell i = v - d/2, j = i+d with v = (tid+OFF) mod NT.  The cell of the same
 // thread two diagonals later is (i-1, j+1), the cell that encloses it — which makes the interior-loop search
 // incremental (below) with all of its state in registers.
@@ -58,10 +61,10 @@
 #define SF_FAST_ROWTAB 1  // rolling-row offsets from a table (scalar loads, SfFastRows) instead of per-row ring arithmetic
 #endif
 #ifndef SF_FAST_UNPACK
-#define SF_FAST_UNPACK 1  // split steps (W = 120 instantiation): the generic-loop recurrence on full-rate 16-bit instructions (SfHU)
+#define SF_FAST_UNPACK 1  // narrow kernels, from d0 = 36 on: the generic-loop recurrence on full-rate 16-bit instructions (SfHU)
 #endif
 #ifndef SF_LOOPS_BY_KIND
-#define SF_LOOPS_BY_KIND 1
+#define SF_LOOPS_BY_KIND 1  // one loop per kind of step instead of one loop with the kinds as branches (0: the round-4 structure)
 #endif
 #ifndef SF_UNP_PB
 #define SF_UNP_PB 4  // size pairs per batch of reads in the unpacked recurrence (3 / 4 / 6 / 12: 58.0 / 57.5 / 58.6 / 58.3 ms per 262 144 folds)
@@ -470,13 +473,14 @@ static inline void sf_emul_check_ci_row(const int16_t *row_ptr, long lane_entrie
 //                dependent LDS round trips
 enum { SF_SEC_P1 = 1, SF_SEC_HELP = 2, SF_SEC_DML = 4, SF_SEC_FIN = 8, SF_SEC_C0 = 16, SF_SEC_ALL = 31, SF_SEC_PRE = 32,
        SF_SEC_POST = 64 };
-// UNP (the split steps of the W = 120 instantiation): the per-size minima of the generic-loop recurrence one int16 per register
+// UNP (the narrow kernels' steps from d0 = 36 on): the per-size minima of the generic-loop recurrence one int16 per register
 // instead of two.  On MI355X every packed (VOP3P) instruction and the v_lshl_or that packs two 16-bit reads issue at half the rate
 // of the 16-bit VOP2 forms v_min_i16 / v_add_u16 (profiles/r04/mfe_issue_rates.json), so a size pair costs 5 half-rate + 1
 // full-rate vector instructions packed and 7 full-rate ones unpacked: 10.6 against 7.4 ns of a SIMD's vector time.  27
-// registers instead of 14 — which only the main waves of the split steps can afford (no special / bulge / 1xn block there): the
-// kernel converts the state once, at the first split step, and runs those steps as a loop of their own (see the kernel).
-// No saturation is needed: every size exists on these diagonals (no guarded weights), and INF16 + a parameter < 32767.
+// registers instead of 14: affordable because the unsplit and the split steps are loops of their own (the kernel converts the
+// state once, where the guarded steps end).  No saturation is needed: every size exists on these diagonals (no guarded weights),
+// and INF16 + a parameter < 32767.  The guarded steps (v_add_i16 clamp: half-rate again) and the wide kernel measured slower
+// with it and stay packed (profiles/r05/EXPERIMENTS.md).
 struct SfHU {
   short v[27];  // v[x]: minimum over the generic candidates of total size x + 4
 };

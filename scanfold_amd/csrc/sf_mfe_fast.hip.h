@@ -52,8 +52,13 @@
 #include "sf_pk16.h"
 
 #define SF_FAST_NR 34
-// even diagonals below this one run the size-tested cell code (some special loops do not exist yet: d <= 11)
-#define SF_FAST_TINY_D0 12
+// even diagonals below this one run the size-tested cell code; from here on the straight-line code with guarded size tables.
+// (12 until round 5 — "some special loops do not exist yet" below d = 12 — but what the straight-line code reads for them are ring rows
+// no diagonal of the fold has written, which every fold initialises to "none"; only the two unpaired sizes 4 / 5 needed a clamp.
+// 8 / 10 / 12: 54.6 / 53.9 / 54.2 ms per 262 144 120-mers, W = 200 55.2 / 52.7 / 52.9 per 65 536)
+#ifndef SF_FAST_TINY_D0
+#define SF_FAST_TINY_D0 10
+#endif
 // even diagonals below this one skip whole batches of loop sizes above the limit (CH); from here to 36 the skipped
 // work is small and the unbroken straight-line code is faster (measured: 20 / 24 / 28 / 36 -> 87.5 / 87.1 / 87.0 / 87.9 ms)
 #define SF_FAST_CHUNK_D0 36
@@ -675,11 +680,16 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
       }
     }
   }
+  // (CH below d = 12: sizes 4 / 5 may not exist yet — their guarded weight is 32767 and the sum must not wrap in the int16 store)
   if (!G || (UCAP >= 5 && umax >= 5)) {
     const int16_t *row = CIROW(5) + i0;
-    HSET(1, sfd_min(row[3], row[4]) + SF_UNI(uNIN, 1));
+    const int e5 = sfd_min(row[3], row[4]) + SF_UNI(uNIN, 1);
+    HSET(1, CH ? sfd_min(e5, 32767) : e5);
   }
-  if (!G || (UCAP >= 4 && umax >= 4)) HSET(0, (CIROW(4) + i0)[3] + SF_UNI(uNIN, 0));
+  if (!G || (UCAP >= 4 && umax >= 4)) {
+    const int e4 = (CIROW(4) + i0)[3] + SF_UNI(uNIN, 0);
+    HSET(0, CH ? sfd_min(e4, 32767) : e4);
+  }
   }
 
   }

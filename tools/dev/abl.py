@@ -82,6 +82,7 @@ VARIANTS = {
                 ("scanfold_amd/csrc/sf_pf_lds.hip.h", '            qa[t] = qbA[SF_LANE_GET(tcol, u_ + 1)]; da[t] = dB1[-u_]; wa[t] = WB[u_]; fa[t] = 0.0;', '            qa[t] = qbA[TCOL_OUT(u_ + 1)]; da[t] = dB1[-u_]; wa[t] = WB[u_]; fa[t] = 0.0;'),
                 ("scanfold_amd/csrc/sf_pf_lds.hip.h", '            qa[t] = qbA[SF_LANE_GET(tcol, u_)]; fa[t] = f1N[SF_PK_ROW(SF_LANE_GET(tpk, u_))];\n            da[t] = d1N2[-u_]; wa[t] = WIL1N[u_];', '            qa[t] = qbA[TCOL_OUT(u_)]; fa[t] = f1N[SF_PK_ROW(SF_LANE_GET(tpk, u_))];\n            da[t] = d1N2[-u_]; wa[t] = WIL1N[u_];'),
                ], []),
+    "tiny8": ([], ["-DSF_FAST_TINY_D0=8"]), "tiny12": ([], ["-DSF_FAST_TINY_D0=12"]),
     "pb4": ([], ["-DSF_UNP_PB=4"]),
     "pb6": ([], ["-DSF_UNP_PB=6"]), "pb12": ([], ["-DSF_UNP_PB=12"]),
     "nounpack": ([], ["-DSF_FAST_UNPACK=0"]),

@@ -151,3 +151,28 @@ def test_cpu_twin_equals_the_oracle(oracle):
         assert np.abs(a["ens_div"] - b["ens_div"]).max() < 1e-9
     arr = np.frombuffer(b"ACGU", dtype=np.uint8)[rng.integers(0, 4, (200, 90))]
     assert (oracle.twin_mfe_batch(arr, 2) == oracle.mfe_batch(arr, 2)).all()
+
+
+def test_native_build_of_the_cpu_engine_is_a_second_instance_with_the_same_results(oracle):
+    """bench.py's cpu_baseline times two builds of the same sources: the portable one and `-O3 -march=native` made on the
+    host that runs it (oracle.build_native: oracle/_native/, stamped with the CPU it was built for, never shipped).  The native
+    build is a separate library instance with its own parameter tables and must give the portable build's results."""
+    import os
+    import numpy as np
+    from scanfold_amd import params
+    L = oracle.lib_native()
+    assert L is not oracle.lib()
+    here = os.path.dirname(os.path.abspath(oracle.__file__))
+    stamp = open(os.path.join(here, "_native", "built_for.txt")).read()
+    assert "-march=native" in stamp and oracle.NATIVE_FLAGS in stamp and stamp == oracle._cpu_stamp()
+    oracle.set_params(params.default_params(), L=L)
+    rng = np.random.default_rng(5)
+    rows = np.frombuffer(b"ACGU", dtype=np.uint8)[rng.integers(0, 4, (4 * 6, 120))]
+    a = oracle.twin_scan_windows(rows, 4, 5, nthreads=2)
+    b = oracle.twin_scan_windows(rows, 4, 5, nthreads=2, L=L)
+    assert (a["energies"] == b["energies"]).all() and a["structure"] == b["structure"] and a["centroid"] == b["centroid"]
+    assert np.abs(a["ens_div"] - b["ens_div"]).max() < 1e-9
+    # the library files of .gitignore / .gpurunignore: the native object must not travel
+    root = os.path.dirname(here)
+    assert "oracle/_native/" in open(os.path.join(root, ".gitignore")).read()
+    assert "oracle/_native/" in open(os.path.join(root, ".gpurunignore")).read()

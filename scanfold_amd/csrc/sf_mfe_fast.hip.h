@@ -1002,7 +1002,9 @@ __device__ __forceinline__ void sf_fast_cell(const SfFastCtx &X, const int d, co
   // ---- publish the cell ----
   const int rbd = slotd * RW + i0;
   int f = SF_FAST_BIG, cx = SF_INF16;
-  if ((SEC & SF_SEC_POST) && type) {
+  if (SEC & SF_SEC_POST) {
+    // (no test of the pair type: a cell that cannot pair has c = "none" and publish terms that are all zero — the stores below then
+    // publish exactly "none" — and the divergent branch was a few dozen cycles of a phase every other wave of the workgroup waits for)
     X.CI[rbd] = (int16_t)(c + sf_lo(pub.a));
     if (!FOLD && slotd == 0) X.CI[SF_FAST_NR * RW + i0] = (int16_t)(c + sf_lo(pub.a));
     const uint32_t bn = sf_pk(c + pub.tau, c + sf_hi(pub.a));  // (CB, C1N)

@@ -105,8 +105,6 @@ VARIANTS = {
     "nofin": ([(FAST, FIN, "        if (false) {")], []),
     # what the main waves' post-barrier work costs, piece by piece
     "nofixupS": ([(FAST, "      if (grp == 0 && valid && !helper && !dmlw) {", "      if (!split && grp == 0 && valid && !helper && !dmlw) {")], []),
-    "finlite": ([(FAST, "  if ((SEC & SF_SEC_POST) && type) {\n    X.CI[rbd] = (int16_t)(c + sf_lo(pub.a));",
-                  "  if ((SEC & SF_SEC_POST) && type) {\n    f = c + sf_lo(pub.b);\n    cx = sfd_min(c + sf_hi(pub.b), SF_INF16);\n  } else if ((SEC & SF_SEC_POST) && !type) {\n  } else if (false) {\n    X.CI[rbd] = (int16_t)(c + sf_lo(pub.a));")], []),
     "noscratchS": ([(FAST, "  X.cg[SF_CGIDX(i, j)] = (int16_t)cx;", "  if (!(SEC & SF_SEC_POST)) X.cg[SF_CGIDX(i, j)] = (int16_t)cx;")], []),
     # the phases before the split steps
     "noG": ([(FAST, CELLS, "      if (d0 >= SF_FAST_TINY_D0 && __ballot(valid)) {\n        if (DO_G && d0 < 8)")], []),

@@ -40,17 +40,38 @@
 #define SF_PFL_SLOTS 128
 #define SF_PFL_PAD 32
 #define SF_PFL_LDS_LIMIT (160 * 1024)
+#define SF_PFL_NZP 9  // partial-sum vectors of a column: four teams, four parts of qm / R1, team 1's share of the multiloop sum
+// Outside pass, R1 (sf_pf_lds_kernel): columns per block of the blocked evaluation; the share of team 3's multiloop sum that team 1
+// takes (blocks of eight terms: (l - MLS0) / MLS1, none in a column that starts an R1 block with more than MLSX terms per row)
+#ifndef SF_PFL_RB
+#define SF_PFL_RB 8
+#endif
+#ifndef SF_PFL_MLS0
+#define SF_PFL_MLS0 30
+#define SF_PFL_MLS1 24
+#define SF_PFL_MLSX 16
+#endif
 // A per-column table of wave-uniform values, one entry per lane, read back with v_readlane (no LDS round trip
 // per use).  The table is filled outside divergent control flow.  The CPU emulation keeps it as a plain array.
 // (SF_EMUL cannot see the hazard the pinned load guards against — stale entries in inactive lanes; the v_readlane path runs under
 // tests/test_gpu_parity.py::test_traceback_and_partition_function_parity, test_scan_step_one_shares_inside_tables and the every-width sweep)
 #ifdef SF_EMUL
 #define SF_LANE_TABLE(name, L, expr) int name[64]; for (int L = 0; L < 64; L++) name[L] = (expr)
+#define SF_LANE_TABLE_DECL(name) int name[64]
+#define SF_LANE_TABLE_SET(name, L, expr) for (int L = 0; L < 64; L++) name[L] = (expr)
+#define SF_LANE_TABLE_LOAD(name, L, expr) for (int L = 0; L < 64; L++) name[L] = (expr)
+#define SF_LANE_TABLE_PIN(name) (void)0
 #define SF_LANE_GET(name, idx) name[idx]
 #else
 // (the empty asm pins the load here, with every lane active: the compiler must not sink it into the divergent
 // region where the entries are read back, or inactive lanes would hold stale values)
 #define SF_LANE_TABLE(name, L, expr) int name; { const int L = threadIdx.x & 63; name = (expr); asm volatile("" : "+v"(name)); }
+#define SF_LANE_TABLE_DECL(name) int name
+#define SF_LANE_TABLE_SET(name, L, expr) { const int L = threadIdx.x & 63; name = (expr); asm volatile("" : "+v"(name)); }
+// (the two halves apart: the load issued where every lane is active, the pin — still outside divergent control flow — later, so
+// that independent work sits between the read and the wait for it)
+#define SF_LANE_TABLE_LOAD(name, L, expr) { const int L = threadIdx.x & 63; name = (expr); }
+#define SF_LANE_TABLE_PIN(name) asm volatile("" : "+v"(name))
 #define SF_LANE_GET(name, idx) __builtin_amdgcn_readlane(name, idx)
 #endif
 // Sizes UHI down to ULO in batches of NB: LOAD (fills qa[t], fa[t], da[t], wa[t] for size u) for a whole batch, then USE for
@@ -80,7 +101,7 @@
 // pairs: a byte each for positions 0..W+1)
 __host__ __device__ inline size_t sf_pfl_lds_bytes(int W, bool hc = false) {
   const size_t NC = (size_t)(W - 4) * (W - 3) / 2, RP = W + 2 * SF_PFL_PAD, VW = W + 8;
-  const size_t dbl = 2 * NC + 12 * RP + 3 * 625 + 2 * VW + 8 + 6 * VW + 7 * VW + (W + 2) + (W + 3) + 16 + (W + 8);
+  const size_t dbl = 2 * NC + 12 * RP + 3 * 625 + 2 * VW + 8 + 6 * VW + SF_PFL_NZP * VW + (W + 2) + (W + 3) + 16 + (W + 8);
   return dbl * sizeof(double) + 2 * (size_t)(W + 2) * sizeof(int) + (size_t)(W + 8) + 64 + (hc ? (size_t)((3 * (W + 2) + 7) & ~7) : 0);
 }
 // doubles per workgroup of the shared-inside state: qb, qm, derived buffers, qm1, 27 registers per centre slot
@@ -138,8 +159,8 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
   double *FAC = DER + 12 * RP;    // [3][25][25] family-A weights
   double *QM1 = FAC + 3 * 625;    // [2][VW]
   double *RV = QM1 + 2 * VW + 8;  // R0[2], R1[2], R01[2], each VW, row r at r + 8 (rows <= 0 stay 0)
-  double *ZP = RV + 6 * VW;       // [4 teams][VW] partial sums of the current column, [4..6] = the three parts of qm / R1
-  double *q5 = ZP + 7 * VW;       // [W+2]
+  double *ZP = RV + 6 * VW;       // [4 teams][VW] partial sums of the current column, [4..7] = the parts of qm / R1, [8] = team 1's part of the multiloop sum
+  double *q5 = ZP + SF_PFL_NZP * VW;  // [W+2]
   double *q3 = q5 + (W + 2);      // [W+3]
   double *red = q3 + (W + 3);     // [16]
   // size weights and MLbase^a: the same for every lane — scalar loads from the parameter block (they used to be LDS copies read
@@ -195,7 +216,7 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
       }
     }
     for (int x = tid; x < 12 * RP; x += SF_PFL_NT) DER[x] = 0.0;
-    for (int x = tid; x < 15 * VW + 8; x += SF_PFL_NT) QM1[x] = 0.0;  // QM1, the six R vectors, the partial sums
+    for (int x = tid; x < (8 + SF_PFL_NZP) * VW + 8; x += SF_PFL_NT) QM1[x] = 0.0;  // QM1, the six R vectors, the partial sums
     __syncthreads();
     for (int x = tid; x <= W + 1; x += SF_PFL_NT) {
       const int cf = S[x] * 5 + (x <= W ? S[x + 1] : 0), cb = S[x] * 5 + (x >= 1 ? S[x - 1] : 0);
@@ -588,6 +609,13 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
 #pragma unroll
     for (int u = 0; u < 27; u++) H[u] = 0.0;
     double mbd = 0.0, cd = 0.0;
+    double racc[2] = {0.0, 0.0};  // the block sums of R1 for this team's two columns of the block, row kf
+    // lane tables, entry L: column min(l+L, W).  Those of column l-1 are fetched while column l's results are written (after the
+    // first barrier): a column does not start with an LDS round trip every wave waits for
+    SF_LANE_TABLE_DECL(tpk);
+    SF_LANE_TABLE_DECL(tcol);
+    SF_LANE_TABLE_SET(tpk, L, BWD[sfd_min(W + L, W)]);
+    SF_LANE_TABLE_SET(tcol, L, W + L <= W ? COFF(W + L) : ZOFF);
     for (int l = W; l >= SFD_TURN + 2; l--) {
       const int s = (l <= c - 1) ? c : c + SF_PFL_SLOTS;
       const int k = s - l, d = l - k;
@@ -596,19 +624,26 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
       const double qbkl = (valid && team != 0) ? QBC(k, l) : 0.0;  // qb[k,l]: replaced by ob[k,l] at the end of this column
       const double *R1c = RV + (2 + (l & 1)) * VW, *R01c = RV + (4 + (l & 1)) * VW, *R0c = RV + (l & 1) * VW;
       double *R0n = RV + ((l & 1) ^ 1) * VW, *R1n = RV + (2 + ((l & 1) ^ 1)) * VW, *R01n = RV + (4 + ((l & 1) ^ 1)) * VW;
-      // lane tables, entry L: column min(l+L, W)
-      SF_LANE_TABLE(tpk, L, BWD[sfd_min(l + L, W)]);
-      SF_LANE_TABLE(tcol, L, l + L <= W ? COFF(l + L) : ZOFF);
       const bool r3 = k - 3 >= 1, r2 = k - 2 >= 1;  // the row exists
-      // R1 of the next column l-1, row k: closers (k, m), m >= l+5, right part qm[l, m-1]; the range of m is the
-      // same for every row: team 1 takes its first half, teams 3 and 2 a quarter each (shares from the measured load of the teams)
-      auto r1_part = [&](const int part) -> double {
+      // carried across the barrier by teams 1-3 (looked up again there, they were three dependent LDS round trips at the head of a
+      // phase every wave waits for): the cell's pair type; the cell's weights from the outside-orientation tables, R0 of this column
+      int typeC = 0;
+      double fc0 = 0.0, fc1 = 0.0;
+      // R1 of the next column l-1, row kr: R1[kr] = sum_{m >= l+5} w(kr,m) qm[l,m-1], w(kr,m) = ob[kr,m] x the closing weight of (kr,m)
+      // — the product of a matrix that is final once column m is (w) with the rows of qm, which the inside pass left complete.  It
+      // used to be evaluated column by column (~30 instructions per term: the largest single item of the outside pass); now it is
+      // evaluated for a block of RB = 8 columns (l = r0, r0-1, .., r0-7) when column r0 starts: a thread owns the FIXED row kf (its
+      // index in the team + 1), fetches w(kf,m), m > r0, once and adds it to the sums of two of the block's columns — each team has
+      // its two, no exchange —, each sum with its own row of qm, held a column per lane and read with v_readlane (entries the row
+      // does not have, m < r+5, are zeros).  What a block cannot contain — the terms m = l+5 .. r0 of its last three columns, one to
+      // three per row — is added when the column comes (r1_part).  The owner of a column writes R1 before the barrier.
+      const int rblk = (W - l) % SF_PFL_RB, r0 = l + rblk;
+      const int nblk = sfd_max(l - 10 + 7, 0) >> 3;  // blocks of eight terms of the longest row's multiloop sum
+      const int mlblk1 = (rblk == 0 && W - l - 4 > SF_PFL_MLSX) ? 0 : sfd_min(sfd_max(l - SF_PFL_MLS0, 0) / SF_PFL_MLS1, nblk >> 1);
+      const int mlsplit = 6 + 8 * (nblk - mlblk1);  // team 3: a < mlsplit, team 1: the rest
+      auto r1_part = [&](const int kr, int m, const int mhi) -> double {
         double r1 = 0.0, r1b = 0.0;
-        const double *fW = FAC + 1250 + SF_PK_CODE(FWD[k]);
-        const int mlo = l + SFD_TURN + 2, len = sfd_max(W + 1 - mlo, 0);
-        const int mmid = mlo + ((len >> 1) & ~3), m3q = mmid + ((sfd_max(W + 1 - mmid, 0) >> 1) & ~3);
-        int m = part == 0 ? mlo : (part == 1 ? mmid : m3q);
-        const int mhi = part == 0 ? mmid - 1 : (part == 1 ? m3q - 1 : W);
+        const double *fW = FAC + 1250 + SF_PK_CODE(FWD[sfd_min(kr, W)]);
         // (four terms per trip, their reads issued together; the neighbour codes — the address of a term's weight — are
         // fetched one trip ahead)
         int bw[4];
@@ -619,7 +654,7 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
           int bn[4];
 #pragma unroll
           for (int t = 0; t < 4; t++) {
-            q[t] = QBC(k, m + t);
+            q[t] = QBC(kr, m + t);
             f[t] = fW[SF_PK_ROW(bw[t])];
             g[t] = QMD(m + t - 1 - l, l);
             bn[t] = BWD[sfd_min(m + 4 + t, W)];
@@ -630,8 +665,92 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
 #pragma unroll
           for (int t = 0; t < 4; t++) bw[t] = bn[t];
         }
-        for (; m <= mhi; m++) r1 += QBC(k, m) * fW[SF_PK_ROW(BWD[m])] * QMD(m - 1 - l, l);
+        for (; m <= mhi; m++) r1 += QBC(kr, m) * fW[SF_PK_ROW(BWD[m])] * QMD(m - 1 - l, l);
         return r1 + r1b;
+      };
+      auto r1_block = [&](const int kr, const int jb) {
+        const int ln = tid & 63;
+        double g[2][2];  // qm[l-jb-jj, c], column c = lane + 64 h (0 where the entry does not exist)
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++)
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            const int r = l - jb - jj, cq = ln + 64 * h, dd = cq - r;
+            g[jj][h] = (r >= 1 && dd >= SFD_TURN + 1 && cq <= W) ? QMD(dd, r) : 0.0;
+          }
+        racc[0] = racc[1] = 0.0;
+        const double *fW = FAC + 1250 + SF_PK_CODE(FWD[sfd_min(kr, W)]);
+        const double *qp = QB + kr - 1;
+        // four columns m per trip, their reads issued together; the neighbour codes — the address of a term's weight — are fetched
+        // one trip ahead (one m per trip was two dependent LDS round trips per term).  The columns m-1 < 64 and >= 64 as two
+        // loops: which half of the rows of qm a term reads is then a compile-time constant (as a test per term it compiled to ~30
+        // branches per trip).
+        auto half = [&](auto HH, const int mlo, const int mhi) {
+          constexpr int h = decltype(HH)::value;
+          if (mlo > mhi) return;
+          int bw[4];
+#pragma unroll
+          for (int t = 0; t < 4; t++) bw[t] = BWD[sfd_min(mlo + t, mhi)];
+          for (int m = mlo; m <= mhi; m += 4) {
+            double q[4], f[4];
+            int bn[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+              const int mt = sfd_min(m + t, mhi);
+              q[t] = qp[COFF(mt)];
+              f[t] = fW[SF_PK_ROW(bw[t])];
+              bn[t] = BWD[sfd_min(m + 4 + t, mhi)];
+            }
+            SF_SCHED_FENCE();
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+              const double w = (m + t <= mhi) ? q[t] * f[t] : 0.0;
+              const int cq = sfd_min(m + t, mhi) - 1 - 64 * h;
+              racc[0] += w * sf_lane_read_f64(g[0][h], cq);
+              racc[1] += w * sf_lane_read_f64(g[1][h], cq);
+              bw[t] = bn[t];
+            }
+          }
+        };
+        half(std::integral_constant<int, 0>{}, l + 1, sfd_min(W, 64));
+        half(std::integral_constant<int, 1>{}, sfd_max(l + 1, 65), W);
+      };
+      {
+        static_assert(SF_PFL_RB == 8, "four teams x two columns of a block");
+        const int kf = (tid & (SF_PFL_SLOTS - 1)) + 1;
+        // (the columns with terms left over go to the teams with the lighter roles)
+        const int jb = team == 0 ? 4 : (team == 1 ? 6 : (team == 2 ? 2 : 0));
+        if (rblk == 0) r1_block(kf, jb);
+        if ((rblk >> 1) == (jb >> 1)) {
+          double r1v = (rblk & 1) ? racc[1] : racc[0];
+          if (rblk >= 5) r1v += r1_part(kf, l + SFD_TURN + 2, r0);
+          if (kf <= l - SFD_TURN - 1) R1n[kf] = r1v;
+        }
+      }
+      // (k,l) as a stem of a multiloop closed by (i,m), i < k, m > l: the terms a = k - i in [alo, ahi), eight closers per trip;
+      // the overshoot reads rows <= 0 of R1 / R01, which are 0
+      auto ml_part = [&](const int alo, const int ahi) -> double {
+        double ms = 0.0, ms2 = 0.0;
+        const double *qmr = QM + k, *r1p = R1c + k, *r01p = R01c + k;
+        int off = DOFF(alo - 2) - alo, st = W - alo + 1;  // DOFF(a-2) - a and its increment
+        for (int a = alo; a <= k - 1 && a < ahi; a += 8) {
+          double t0 = 0.0, t1 = 0.0;
+          double mb[8], rv[8], qv[8], sv8[8];
+#pragma unroll
+          for (int t = 0; t < 8; t++) {
+            mb[t] = MLB[a + t - 1]; rv[t] = r1p[-a - t]; qv[t] = qmr[off]; sv8[t] = r01p[-a - t];
+            off += st--;
+          }
+          SF_SCHED_FENCE();
+#pragma unroll
+          for (int t = 0; t < 8; t += 2) {
+            t0 += mb[t] * rv[t] + qv[t] * sv8[t];
+            t1 += mb[t + 1] * rv[t + 1] + qv[t + 1] * sv8[t + 1];
+          }
+          ms += t0;
+          ms2 += t1;
+        }
+        return ms + ms2;
       };
       if (team == 0) {
         if (valid) {
@@ -706,6 +825,9 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
       } else if (team == 1) {
         if (valid) {
           const int type = OWN(k, l);
+          typeC = type;
+          fc0 = FAC[1250 + SF_PK_ROW(BWD[l]) + SF_PK_CODE(FWD[k])];
+          fc1 = R0c[k];
           const int sp1 = S[k - 1];
           const double *dB1 = DERP(2, l + 1) + k - 1;
           const double *qbA = QB + (k > 1 ? k - 2 : 0);  // row k-1 (row 1 for speculative reads)
@@ -720,11 +842,19 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
             if (u_ & 1) gb2 += tt; else gb += tt;
           })
           ZP[VW + k] = (gb + gb2) * (type > 2 ? xTAU : 1.0);  // rtype(type) > 2 <=> type > 2
-          ZP[4 * VW + k] = r1_part(0);
+          // (wave-uniform: the late columns only)
+          ZP[8 * VW + k] = mlblk1 ? ml_part(mlsplit, W) * sfx_mlstem(X, type, sp1, S[l + 1]) : 0.0;
         }
+
       } else if (team == 2) {
         if (valid) {
           const int type = OWN(k, l);
+          typeC = type;
+          {
+            const int fa = SF_PK_ROW(BWD[l]) + SF_PK_CODE(FWD[k]);  // (S[l], S[l-1]) x (S[k], S[k+1])
+            fc0 = FAC[fa];
+            fc1 = FAC[625 + fa];
+          }
           const int rt = sfd_rtype(type);
           const int sp1 = S[k - 1], sq1 = S[l + 1];
           const double w1n = X->mismatch1nI[rt][sq1][sp1];  // device memory: issued before the long sums below
@@ -745,61 +875,38 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
             if (u_ & 1) g2 += tt; else g1 += tt;
           })
           ZP[2 * VW + k] = (g1 + g2) * w1n;
-          ZP[6 * VW + k] = r1_part(2);
         }
       } else {
         if (valid) {
           const int type = OWN(k, l);
+          typeC = type;
           const int sp1 = S[k - 1], sq1 = S[l + 1];
-          // (k,l) as a stem of a multiloop closed by (i,m), i < k, m > l
-          double ms = 0.0, ms2 = 0.0;
+          double ms = 0.0;
           for (int a = 1; a <= sfd_min(k - 1, 5); a++) ms += MLB[a - 1] * R1c[k - a];
-          {
-            // eight closers per trip; the overshoot reads rows <= 0 of R1 / R01, which are 0
-            const double *qmr = QM + k, *r1p = R1c + k, *r01p = R01c + k;
-            int off = -6, st = W - 5;  // DOFF(a-2) - a and its increment, a = 6
-            for (int a = 6; a <= k - 1; a += 8) {
-              double t0 = 0.0, t1 = 0.0;
-              double mb[8], rv[8], qv[8], sv8[8];
-#pragma unroll
-              for (int t = 0; t < 8; t++) {
-                mb[t] = MLB[a + t - 1]; rv[t] = r1p[-a - t]; qv[t] = qmr[off]; sv8[t] = r01p[-a - t];
-                off += st--;
-              }
-              SF_SCHED_FENCE();
-#pragma unroll
-              for (int t = 0; t < 8; t += 2) {
-                t0 += mb[t] * rv[t] + qv[t] * sv8[t];
-                t1 += mb[t + 1] * rv[t + 1] + qv[t + 1] * sv8[t + 1];
-              }
-              ms += t0;
-              ms2 += t1;
-            }
-          }
-          ZP[3 * VW + k] = (ms + ms2) * sfx_mlstem(X, type, sp1, sq1);
-          ZP[5 * VW + k] = r1_part(1);
+          ms += ml_part(6, mlsplit);
+          ZP[3 * VW + k] = ms * sfx_mlstem(X, type, sp1, sq1);
         }
       }
       __syncthreads();
+      SF_LANE_TABLE_LOAD(tpk, L, BWD[sfd_min(l - 1 + L, W)]);
+      SF_LANE_TABLE_LOAD(tcol, L, l - 1 + L <= W ? COFF(l - 1 + L) : ZOFF);
       // The column's results, shared out: team 2 writes the tables the next column's loops read, team 1 the multiloop vectors,
       // team 3 the pair probability and what hangs on it (each forms the cell's sum from the partial sums itself; qb[k,l],
       // which team 2 overwrites here, was read before the barrier).
       if (team != 0 && valid) {
-        const int type = OWN(k, l);
+        const int type = typeC;
         double o = 0.0;
-        if (type && qbkl != 0.0) o = inner ? (ZP[k] + ZP[VW + k]) + (ZP[2 * VW + k] + ZP[3 * VW + k]) : ZP[k];
-        const int fa = SF_PK_ROW(BWD[l]) + SF_PK_CODE(FWD[k]);  // (S[l], S[l-1]) x (S[k], S[k+1]): LDS, not device memory
+        if (type && qbkl != 0.0) o = inner ? (ZP[k] + ZP[VW + k]) + (ZP[2 * VW + k] + (ZP[3 * VW + k] + ZP[8 * VW + k])) : ZP[k];
         if (team == 2) {
           QBC(k, l) = o;
-          DERP(0, l)[k] = type ? o * FAC[fa] : 0.0;
-          DERP(1, l)[k] = type ? o * FAC[625 + fa] : 0.0;
+          DERP(0, l)[k] = type ? o * fc0 : 0.0;
+          DERP(1, l)[k] = type ? o * fc1 : 0.0;
           DERP(2, l)[k] = (type > 2) ? o * xTAU : o;
         } else if (team == 1) {
-          const double w = type ? o * FAC[1250 + fa] : 0.0;
-          const double r0 = w + xMLbase * R0c[k];
-          const double r1 = (ZP[5 * VW + k] + ZP[6 * VW + k]) + ZP[4 * VW + k];
+          const double w = type ? o * fc0 : 0.0;
+          const double r0 = w + xMLbase * fc1;
+          const double r1 = R1n[k];  // (written before the barrier by the thread that owns row k)
           R0n[k] = r0;
-          R1n[k] = r1;
           R01n[k] = r0 + r1;
         } else {
           const double p = o * qbkl / Z;
@@ -810,6 +917,8 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
           } else cd += p;
         }
       }
+      SF_LANE_TABLE_PIN(tpk);
+      SF_LANE_TABLE_PIN(tcol);
       __syncthreads();
     }
     mbd = sf_block_sum(mbd, red);

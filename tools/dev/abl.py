@@ -59,7 +59,61 @@ STAMP_PATCHES = [
      "  g.prof_on = true;\n  HIPCHK(hipMemset((char *)g.status.p + 256, 0, 64 * 4 * 8 * 8));"),
 ]
 
+# "pfstamps": the same for sf_pf_lds_kernel.  Lane 0 of every wave of every 64th workgroup adds, per wave (8 waves x 64 slots of
+# cycles behind the status word at byte 32768): outside pass per column, in four buckets of the column l (bucket (l - 1) / 30, eight
+# slots each) — a point inside the own work [0] (team 0: after the recurrence batches; teams 1-3: before the R1 share), own work [1],
+# exit of the first barrier [2], end of the post-barrier work [3], exit of the second barrier [4], columns [5]; the inside columns
+# [32..36] (own, barrier 1, post, barrier 2, columns); per fold (wave 0 only) — reload [40], inside loop [41], park + exterior + tables
+# [42], outside loop [43], reductions [44], folds [45].
+# launch_pf waits for the kernel and appends the sums to $SF_STAMP_OUT (tools/dev/pf_stamp_report.py).
+PFL = "scanfold_amd/csrc/sf_pf_lds.hip.h"
+PFSTAMP_PATCHES = [
+    (PFL, "      if (team == 0) {\n        if (valid) {\n          const double *dI3 = DERP(0, l + 3) + k;",
+     "      if (SFL) atomicAdd(SFB + 0, (unsigned long long)(clock64() - SFT0));\n"
+     "      if (team == 0) {\n        if (valid) {\n          const double *dI3 = DERP(0, l + 3) + k;"),
+    (PFL, "    const bool nbL = SH && pos > 0, nbR = SH && pos + W < L;\n    __syncthreads();\n",
+     "    const bool nbL = SH && pos > 0, nbR = SH && pos + W < L;\n    __syncthreads();\n"
+     "    unsigned long long *const SFP = (unsigned long long *)((char *)status + 32768) + (tid >> 6) * 64;\n"
+     "    const bool SFL = status && (tid & 63) == 0 && (blockIdx.x & 63) == 5;\n"
+     "    const bool SFL0 = SFL && tid == 0;\n"
+     "    long long SFF = 0;\n"
+     "#define SF_PH(slot) if (SFL0) { const long long t_ = (long long)clock64(); atomicAdd(SFP + (slot), (unsigned long long)(t_ - SFF)); SFF = t_; }\n"),
+    (PFL, "    double H[27];\n#pragma unroll\n    for (int u = 0; u < 27; u++) H[u] = 0.0;\n    if (resume) {",
+     "    double H[27];\n#pragma unroll\n    for (int u = 0; u < 27; u++) H[u] = 0.0;\n    SFF = SFL ? (long long)clock64() : 0;\n    if (resume) {"),
+    (PFL, "    for (int j = resume ? W - step + 1 : SFD_TURN + 2; j <= W + 1; j++) {\n",
+     "    SF_PH(40)\n    for (int j = resume ? W - step + 1 : SFD_TURN + 2; j <= W + 1; j++) {\n      const long long SFT0 = SFL ? (long long)clock64() : 0;\n"),
+    (PFL, "      __syncthreads();\n      if (team == 2 && qvalid) QMD(dq, i) = ZP[5 * VW + i] + ZP[4 * VW + i];",
+     "      if (SFL) atomicAdd(SFP + 32, (unsigned long long)(clock64() - SFT0));\n      __syncthreads();\n"
+     "      if (SFL) atomicAdd(SFP + 33, (unsigned long long)(clock64() - SFT0));\n"
+     "      if (team == 2 && qvalid) QMD(dq, i) = ZP[5 * VW + i] + ZP[4 * VW + i];"),
+    (PFL, "        qm1c[i] = m1;\n      }\n      __syncthreads();\n    }\n",
+     "        qm1c[i] = m1;\n      }\n      if (SFL) atomicAdd(SFP + 34, (unsigned long long)(clock64() - SFT0));\n      __syncthreads();\n"
+     "      if (SFL) { atomicAdd(SFP + 35, (unsigned long long)(clock64() - SFT0)); atomicAdd(SFP + 36, 1ull); }\n    }\n    SF_PH(41)\n"),
+    (PFL, "    for (int l = W; l >= SFD_TURN + 2; l--) {\n",
+     "    SF_PH(42)\n    for (int l = W; l >= SFD_TURN + 2; l--) {\n      const long long SFT0 = SFL ? (long long)clock64() : 0;\n"
+     "      unsigned long long *const SFB = SFP + ((l - 1) / 30) * 8;\n"),
+    (PFL, "      __syncthreads();\n      SF_LANE_TABLE_LOAD(tpk, L, BWD[sfd_min(l - 1 + L, W)]);",
+     "      if (SFL) atomicAdd(SFB + 1, (unsigned long long)(clock64() - SFT0));\n      __syncthreads();\n"
+     "      if (SFL) atomicAdd(SFB + 2, (unsigned long long)(clock64() - SFT0));\n      SF_LANE_TABLE_LOAD(tpk, L, BWD[sfd_min(l - 1 + L, W)]);"),
+    (PFL, "          } else cd += p;\n        }\n      }\n      SF_LANE_TABLE_PIN(tpk);\n      SF_LANE_TABLE_PIN(tcol);\n      __syncthreads();\n    }\n",
+     "          } else cd += p;\n        }\n      }\n      SF_LANE_TABLE_PIN(tpk);\n      SF_LANE_TABLE_PIN(tcol);\n      if (SFL) atomicAdd(SFB + 3, (unsigned long long)(clock64() - SFT0));\n      __syncthreads();\n"
+     "      if (SFL) { atomicAdd(SFB + 4, (unsigned long long)(clock64() - SFT0)); atomicAdd(SFB + 5, 1ull); }\n    }\n    SF_PH(43)\n"),
+    (PFL, "      if (centroid_dist) centroid_dist[fold] = cd;\n    }\n",
+     "      if (centroid_dist) centroid_dist[fold] = cd;\n    }\n    SF_PH(44)\n    if (SFL0) atomicAdd(SFP + 45, 1ull);\n"),
+    (HOST, "    int rc = ensure(g.status, sizeof(int));\n    if (rc) return rc;\n    HIPCHK(hipMemset(g.status.p, 0, sizeof(int)));",
+     "    int rc = ensure(g.status, 65536);\n    if (rc) return rc;\n    HIPCHK(hipMemset(g.status.p, 0, 65536));"),
+    (HOST, "                     d_dG, d_mbd, d_cen, d_cd, d_tr, L, win0, step, run_len, share, (const char *)nullptr, (int *)nullptr);\n",
+     "                     d_dG, d_mbd, d_cen, d_cd, d_tr, L, win0, step, run_len, share, (const char *)nullptr, (int *)g.status.p);\n"
+     "    if (const char *so = getenv(\"SF_STAMP_OUT\")) {\n      static unsigned long long hb[8 * 64];\n      HIPCHK(hipStreamSynchronize(st));\n"
+     "      HIPCHK(hipMemcpy(hb, (char *)g.status.p + 32768, sizeof hb, hipMemcpyDeviceToHost));\n"
+     "      HIPCHK(hipMemset((char *)g.status.p + 32768, 0, sizeof hb));\n      if (FILE *f = fopen(so, \"a\")) {\n"
+     "        fprintf(f, \"launch n %d W %d run_len %d\\n\", n, W, run_len);\n"
+     "        for (int k = 0; k < 8; k++) { for (int q = 0; q < 64; q++) fprintf(f, \"%llu \", hb[k * 64 + q]); fprintf(f, \"\\n\"); }\n"
+     "        fclose(f);\n      }\n    }\n"),
+]
+
 VARIANTS = {
+    "pfstamps": (PFSTAMP_PATCHES, []),
     "stamps": (STAMP_PATCHES, []),
     # name: (patches, flags)
     "head": ([], []),

@@ -48,7 +48,7 @@
 #endif
 #ifndef SF_PFL_MLS0
 #define SF_PFL_MLS0 30
-#define SF_PFL_MLS1 24
+#define SF_PFL_MLS1 12
 #define SF_PFL_MLSX 16
 #endif
 // A per-column table of wave-uniform values, one entry per lane, read back with v_readlane (no LDS round trip
@@ -691,24 +691,42 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
           int bw[4];
 #pragma unroll
           for (int t = 0; t < 4; t++) bw[t] = BWD[sfd_min(mlo + t, mhi)];
-          for (int m = mlo; m <= mhi; m += 4) {
+          // (whole trips without any clamping, the last — partial — one with)
+          int m = mlo, coff = COFF(mlo);
+          for (; m + 3 <= mhi; m += 4) {
             double q[4], f[4];
             int bn[4];
 #pragma unroll
             for (int t = 0; t < 4; t++) {
-              const int mt = sfd_min(m + t, mhi);
-              q[t] = qp[COFF(mt)];
+              q[t] = qp[coff];
+              coff += m + t - 4;  // COFF(x+1) - COFF(x) = x - 4
               f[t] = fW[SF_PK_ROW(bw[t])];
-              bn[t] = BWD[sfd_min(m + 4 + t, mhi)];
+              bn[t] = BWD[m + 4 + t];  // (up to three entries past mhi <= W: inside the table, W+2 entries, or the array behind it; not used)
             }
             SF_SCHED_FENCE();
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+              const double w = q[t] * f[t];
+              const int cq = m + t - 1 - 64 * h;
+              racc[0] += w * sf_lane_read_f64(g[0][h], cq);
+              racc[1] += w * sf_lane_read_f64(g[1][h], cq);
+              bw[t] = bn[t];
+            }
+          }
+          if (m <= mhi) {
+            double q[4], f[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+              const int mt = sfd_min(m + t, mhi);
+              q[t] = qp[COFF(mt)];
+              f[t] = fW[SF_PK_ROW(t == 0 ? bw[0] : BWD[mt])];
+            }
 #pragma unroll
             for (int t = 0; t < 4; t++) {
               const double w = (m + t <= mhi) ? q[t] * f[t] : 0.0;
               const int cq = sfd_min(m + t, mhi) - 1 - 64 * h;
               racc[0] += w * sf_lane_read_f64(g[0][h], cq);
               racc[1] += w * sf_lane_read_f64(g[1][h], cq);
-              bw[t] = bn[t];
             }
           }
         };

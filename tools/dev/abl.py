@@ -114,6 +114,12 @@ PFSTAMP_PATCHES = [
 
 VARIANTS = {
     "pfstamps": (PFSTAMP_PATCHES, []),
+    # partition function, outside pass: team 1's share of team 3's multiloop sum, blocks of eight terms: (l - MLS0) / MLS1
+    "pfmls30_8": ([], ["-DSF_PFL_MLS0=30", "-DSF_PFL_MLS1=8", "-DSF_PFL_MLSX=16"]),
+    "pfmls20_10": ([], ["-DSF_PFL_MLS0=20", "-DSF_PFL_MLS1=10", "-DSF_PFL_MLSX=16"]),
+    "pfmls10_12": ([], ["-DSF_PFL_MLS0=10", "-DSF_PFL_MLS1=12", "-DSF_PFL_MLSX=16"]),
+    "pfmls40_8": ([], ["-DSF_PFL_MLS0=40", "-DSF_PFL_MLS1=8", "-DSF_PFL_MLSX=16"]),
+    "pfmlsx999": ([], ["-DSF_PFL_MLS0=30", "-DSF_PFL_MLS1=12", "-DSF_PFL_MLSX=999"]),
     "stamps": (STAMP_PATCHES, []),
     # name: (patches, flags)
     "head": ([], []),

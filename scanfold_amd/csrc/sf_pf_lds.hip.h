@@ -42,14 +42,13 @@
 #define SF_PFL_LDS_LIMIT (160 * 1024)
 #define SF_PFL_NZP 9  // partial-sum vectors of a column: four teams, four parts of qm / R1, team 1's share of the multiloop sum
 // Outside pass, R1 (sf_pf_lds_kernel): columns per block of the blocked evaluation; the share of team 3's multiloop sum that team 1
-// takes (blocks of eight terms: (l - MLS0) / MLS1, none in a column that starts an R1 block with more than MLSX terms per row)
+// takes (blocks of eight terms: (l - MLS0) / MLS1)
 #ifndef SF_PFL_RB
 #define SF_PFL_RB 8
 #endif
 #ifndef SF_PFL_MLS0
 #define SF_PFL_MLS0 30
 #define SF_PFL_MLS1 12
-#define SF_PFL_MLSX 16
 #endif
 // A per-column table of wave-uniform values, one entry per lane, read back with v_readlane (no LDS round trip
 // per use).  The table is filled outside divergent control flow.  The CPU emulation keeps it as a plain array.
@@ -110,6 +109,14 @@ static inline bool sf_pfl_supported(int W) {
   return W >= 16 && W <= 128 && 2 * W - 4 < 2 * SF_PFL_SLOTS && sf_pfl_lds_bytes(W) <= SF_PFL_LDS_LIMIT;  // (exterior sweeps: two columns per lane)
 }
 
+// v of lane l (l wave-uniform), 32-bit
+__device__ __forceinline__ int sf_lane_read_i32(const int v, const int l) {
+#ifdef SF_EMUL
+  return __shfl(v, l);
+#else
+  return __builtin_amdgcn_readlane(v, l);
+#endif
+}
 // v of lane l (l wave-uniform), 64-bit
 __device__ __forceinline__ double sf_lane_read_f64(const double v, const int l) {
 #ifdef SF_EMUL
@@ -503,107 +510,149 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
       __syncthreads();
     }
 
-    if (keep) {  // the inside state for the next window of the run (nothing below reads sv)
-      // (qb — about to be overwritten by the outside values —, the derived buffers, qm1; qm stays where it is: 54 of the 156 kB)
-      for (int x = tid; x < NC; x += SF_PFL_NT) sv[x] = QB[x];
-      for (int x = SV_DER + tid; x < 2 * NC + 12 * RP + 2 * VW + 8; x += SF_PFL_NT)
-        sv[x] = x < SV_QM1 ? DER[x - SV_DER] : QM1[x - SV_QM1];
-      if (team == 0) {
-#pragma unroll
-        for (int u = 0; u < 27; u++) sv[SV_H + c * 27 + u] = H[u];
-      }
-    }
     // ================= exterior =================
     // q5[j] = q5[j-1] + sum_i q5[i-1] qb[i,j] ExtLoop(i,j) and its mirror image q3, each by ONE wave as a sweep
     // without any reduction across lanes (the block-wide sum + barrier per column this replaces took 15 % of a
     // fold): wave 0 walks the rows i upwards with a lane per column j, P[j] += q5[i-1] qb[i,j] w(i,j), where
     // q5[i-1] = q5[i-2] + P[i-1] is final by then (column i-1 only has rows <= i-5) and comes from its lane by
     // v_readlane; wave 1 walks the columns downwards with a lane per row, q3[j+1] from the lane of row j+1.
-    // w(i,j) from a 30 x 30 table over (S[j], S[j+1] or "none") x (S[i], S[i-1] or "none"), built in the FAC area
-    // (its inside-orientation tables are dead, the outside ones are built after this).
+    // w(i,j) from a 30 x 30 table over (S[j], S[j+1] or "none") x (S[i], S[i-1] or "none"), built in the partial-sum area (idle
+    // between the passes) where that holds it: the other six waves then park the inside state, build the outside pass's weight
+    // tables in FAC and clear the derived buffers WHILE the two sweeps run (one after the other these were 7 % of a fold).
+    const bool ovl = SF_PFL_NZP * VW >= 900;
+    double *const EXT = ovl ? ZP : FAC;  // (FAC: its inside-orientation tables are dead, the outside ones are built after the sweeps)
+    auto outside_tables = [&](const int t0, const int tn) {
+      // family-A weights, outside orientation: row = nucleotides at the enclosing pair's column l' (S[l'],
+      // S[l'-1]), entry = its row k' (S[k'], S[k'+1]); third table = multiloop closing weight of (k', l')
+      for (int e = t0; e < 625; e += tn) {
+        const int b = e / 25, f = e - b * 25;
+        const int a = f / 5, a1 = f - a * 5, bs = b / 5, b1 = b - bs * 5;
+        const int t = D->pair[a][bs];
+        FAC[e] = t ? X->mismatchI[t][a1][b1] : 0.0;
+        FAC[625 + e] = t ? X->mismatch1nI[t][a1][b1] : 0.0;
+        FAC[1250 + e] = t ? X->MLclosing * sfx_mlstem(X, sfd_rtype(t), b1, a1) : 0.0;
+      }
+    };
     for (int e = tid; e < 900; e += SF_PFL_NT) {
       const int cf = e / 30, cb = e - cf * 30;
       const int sj = cf / 6, s3 = cf - sj * 6, si = cb / 6, s5 = cb - si * 6;
       const int t = (si < 5 && sj < 5) ? D->pair[si][sj] : 0;
-      FAC[e] = t ? sfx_extloop(X, t, s5 < 5 ? s5 : -1, s3 < 5 ? s3 : -1) : 0.0;
+      EXT[e] = t ? sfx_extloop(X, t, s5 < 5 ? s5 : -1, s3 < 5 ? s3 : -1) : 0.0;
     }
     __syncthreads();
-    if (tid < 128) {
+    if (tid >= 128) {
+      const int ht = tid - 128;
+      constexpr int HN = SF_PFL_NT - 128;
+      if (keep) {  // the inside state for the next window of the run (nothing below reads sv)
+        // (qb — about to be overwritten by the outside values —, the derived buffers, qm1; qm stays where it is: 54 of the 156 kB)
+        for (int x = ht; x < NC; x += HN) sv[x] = QB[x];
+        for (int x = SV_DER + ht; x < 2 * NC + 12 * RP + 2 * VW + 8; x += HN)
+          sv[x] = x < SV_QM1 ? DER[x - SV_DER] : QM1[x - SV_QM1];
+      }
+      if (ovl) outside_tables(ht, HN);
+      if (centroid)
+        for (int x = ht; x <= W; x += HN) centroid[(size_t)fold * W1 + x] = (x < W) ? '.' : 0;
+      // the derived buffers of columns W+1 .. W+3 are read as zeros (the inside values they hold were saved above if the next
+      // window wants them: an entry is cleared by the thread that saved it); a column beyond the window's end in qb is the zero
+      // strip: no test per loop size for either
+      for (int x = ht; x < 12 * RP; x += HN) DER[x] = 0.0;
+    } else {
+      if (keep) {  // (team 0 = these two waves: the recurrence registers)
+#pragma unroll
+        for (int u = 0; u < 27; u++) sv[SV_H + c * 27 + u] = H[u];
+      }
       constexpr int NQ = 2;  // sf_pfl_supported: W <= 128
       const int lane = tid & 63;
       const bool fwd = tid < 64;
       double P[NQ];
-      int code[NQ];  // this lane's columns (forward) / rows (backward): table row / entry
+      int codeF[NQ], codeB[NQ];  // this lane's columns: table row; this lane's rows: table entry
 #pragma unroll
       for (int q = 0; q < NQ; q++) {
         const int x = lane + 64 * q + 1;
         P[q] = 0.0;
-        if (x > W) code[q] = 0;
-        else if (fwd) code[q] = (S[x] * 6 + (x < W ? S[x + 1] : 5)) * 30;
-        else code[q] = S[x] * 6 + (x > 1 ? S[x - 1] : 5);
+        codeF[q] = x > W ? 0 : (S[x] * 6 + (x < W ? S[x + 1] : 5)) * 30;
+        codeB[q] = x > W ? 0 : S[x] * 6 + (x > 1 ? S[x - 1] : 5);
       }
       auto owner_sum = [&](const int x) -> double {  // P of column / row x, from the lane that owns it
         const int l = (x - 1) & 63, q = (x - 1) >> 6;
         const double v0 = sf_lane_read_f64(P[0], l), v1 = sf_lane_read_f64(P[1], l);
         return q ? v1 : v0;
       };
+      // A step of either walk is ONE dependent chain of a single wave (~8 cycles per instruction, six waves waiting for it): the
+      // steps are written for as few instructions as possible — which of a lane's two registers a step reads (the owner of the
+      // finished sum, the step's neighbour code) is a compile-time constant per stretch of the walk, q5 / q3 stay in registers (a
+      // lane per entry) until the walk is over, and the half of the columns / rows a step cannot reach is left out.
+      using I0 = std::integral_constant<int, 0>;
+      using I1 = std::integral_constant<int, 1>;
+      double qr[NQ] = {0.0, 0.0};  // q5[lane + 64 h] (forward), q3[lane + 64 h + 1] (backward)
       if (fwd) {
-        double qprev = 1.0;  // q5[i-1] while row i is processed
-        if (lane == 0) q5[0] = 1.0;
-        for (int i = 1; i <= W; i++) {
-          if (i >= 2) {
-            qprev += owner_sum(i - 1);
-            if (lane == 0) q5[i - 1] = qprev;
-          }
-          if (i > W - SFD_TURN - 1) continue;
-          const int cb = S[i] * 6 + (i > 1 ? S[i - 1] : 5);
+        int cj[NQ];  // COFF(j) - 1 of this lane's columns
 #pragma unroll
-          for (int q = 0; q < NQ; q++) {
-            const int j = lane + 64 * q + 1;
-            if (j <= W && i + SFD_TURN + 1 <= j && j - i <= maxd) P[q] += qprev * QBC(i, j) * FAC[code[q] + cb];
+        for (int q = 0; q < NQ; q++) cj[q] = COFF(sfd_max(sfd_min(lane + 64 * q + 1, W), 5)) - 1;
+        double qprev = 1.0;  // q5[i-1] while row i is processed
+        if (lane == 0) qr[0] = 1.0;
+        auto step = [&](const int i, auto OHH, auto XHH, auto CHH, auto Q0) {
+          constexpr int OH = decltype(OHH)::value, XH = decltype(XHH)::value, CH = decltype(CHH)::value, QLO = decltype(Q0)::value;
+          if (i >= 2) {
+            qprev += sf_lane_read_f64(P[OH], (i - 2) & 63);
+            qr[XH] = (lane == ((i - 1) & 63)) ? qprev : qr[XH];
           }
-        }
+          if (i > W - SFD_TURN - 1) return;
+          const int cb = sf_lane_read_i32(codeB[CH], (i - 1) & 63);
+#pragma unroll
+          for (int q = QLO; q < NQ; q++) {
+            const int j = lane + 64 * q + 1;
+            const bool ok = j <= W && i + SFD_TURN + 1 <= j && j - i <= maxd;
+            const double qb = ok ? QB[cj[q] + i] : 0.0;
+            P[q] += qprev * qb * EXT[codeF[q] + cb];
+          }
+        };
+        for (int i = 1; i <= sfd_min(W, 64); i++) step(i, I0{}, I0{}, I0{}, I0{});
+        if (W >= 65) step(65, I0{}, I1{}, I1{}, I1{});
+        for (int i = 66; i <= W; i++) step(i, I1{}, I1{}, I1{}, I1{});
         qprev += owner_sum(W);
+#pragma unroll
+        for (int q = 0; q < NQ; q++)
+          if (lane + 64 * q < W) q5[lane + 64 * q] = qr[q];
         if (lane == 0) q5[W] = qprev;
       } else {
         double qnext = 1.0;  // q3[j+1] while column j is processed
-        if (lane == 0) q3[W + 1] = 1.0;
-        for (int j = W; j >= 1; j--) {
+        auto step = [&](const int j, auto OHH, auto CHH, auto Q1) {
+          constexpr int OH = decltype(OHH)::value, CH = decltype(CHH)::value, QHI = decltype(Q1)::value;
           if (j < W) {
-            qnext += owner_sum(j + 1);
-            if (lane == 0) q3[j + 1] = qnext;
+            qnext += sf_lane_read_f64(P[OH], j & 63);
+            qr[OH] = (lane == (j & 63)) ? qnext : qr[OH];
           }
-          if (j < SFD_TURN + 2) continue;
-          const int cf = (S[j] * 6 + (j < W ? S[j + 1] : 5)) * 30;
+          if (j < SFD_TURN + 2) return;
+          const int cf = sf_lane_read_i32(codeF[CH], (j - 1) & 63);
+          const int cq = COFF(sfd_max(j, 5)) - 1;
 #pragma unroll
-          for (int q = 0; q < NQ; q++) {
+          for (int q = 0; q <= QHI; q++) {
             const int i = lane + 64 * q + 1;
-            if (i + SFD_TURN + 1 <= j && j - i <= maxd) P[q] += QBC(i, j) * FAC[cf + code[q]] * qnext;
+            const bool ok = i + SFD_TURN + 1 <= j && j - i <= maxd;
+            const double qb = ok ? QB[cq + i] : 0.0;
+            P[q] += qb * EXT[cf + codeB[q]] * qnext;
           }
-        }
+        };
+        for (int j = W; j >= 65; j--) step(j, I1{}, I1{}, I1{});
+        if (W >= 64) step(64, I1{}, I0{}, I0{});
+        for (int j = sfd_min(W, 63); j >= 1; j--) step(j, I0{}, I0{}, I0{});
         qnext += owner_sum(1);
-        if (lane == 0) q3[1] = qnext;
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+          const int x = lane + 64 * q + 1;
+          if (x >= 2 && x <= W) q3[x] = qr[q];
+        }
+        if (lane == 0) { q3[W + 1] = 1.0; q3[1] = qnext; }
       }
     }
     __syncthreads();
-    const double Z = q5[W];
-    if (centroid)
-      for (int x = tid; x <= W; x += SF_PFL_NT) centroid[(size_t)fold * W1 + x] = (x < W) ? '.' : 0;
-    // family-A weights, outside orientation: row = nucleotides at the enclosing pair's column l' (S[l'],
-    // S[l'-1]), entry = its row k' (S[k'], S[k'+1]); third table = multiloop closing weight of (k', l')
-    for (int e = tid; e < 625; e += SF_PFL_NT) {
-      const int b = e / 25, f = e - b * 25;
-      const int a = f / 5, a1 = f - a * 5, bs = b / 5, b1 = b - bs * 5;
-      const int t = D->pair[a][bs];
-      FAC[e] = t ? X->mismatchI[t][a1][b1] : 0.0;
-      FAC[625 + e] = t ? X->mismatch1nI[t][a1][b1] : 0.0;
-      FAC[1250 + e] = t ? X->MLclosing * sfx_mlstem(X, sfd_rtype(t), b1, a1) : 0.0;
+    if (!ovl) {
+      outside_tables(tid, SF_PFL_NT);
+      __syncthreads();
     }
-    // the derived buffers of columns W+1 .. W+3 are read as zeros (the inside values they hold were saved above if the next
-    // window wants them); a column beyond the window's end in qb is the zero strip: no test per loop size for either
-    for (int x = tid; x < 12 * RP; x += SF_PFL_NT) DER[x] = 0.0;
+    const double Z = q5[W];
     const int ZOFF = (int)(ZS - QB);
-    __syncthreads();
 
     // ================= outside: columns l descending =================
 #pragma unroll
@@ -639,7 +688,7 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
       // three per row — is added when the column comes (r1_part).  The owner of a column writes R1 before the barrier.
       const int rblk = (W - l) % SF_PFL_RB, r0 = l + rblk;
       const int nblk = sfd_max(l - 10 + 7, 0) >> 3;  // blocks of eight terms of the longest row's multiloop sum
-      const int mlblk1 = (rblk == 0 && W - l - 4 > SF_PFL_MLSX) ? 0 : sfd_min(sfd_max(l - SF_PFL_MLS0, 0) / SF_PFL_MLS1, nblk >> 1);
+      const int mlblk1 = sfd_min(sfd_max(l - SF_PFL_MLS0, 0) / SF_PFL_MLS1, nblk >> 1);
       const int mlsplit = 6 + 8 * (nblk - mlblk1);  // team 3: a < mlsplit, team 1: the rest
       auto r1_part = [&](const int kr, int m, const int mhi) -> double {
         double r1 = 0.0, r1b = 0.0;
@@ -772,6 +821,29 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
       };
       if (team == 0) {
         if (valid) {
+          // (the cell's weights first: a dozen gathers from device memory, in flight while the recurrence below runs — they used to
+          // be fetched after it, an L2 round trip in the longest team's column)
+          const int type = OWN(k, l);
+          // exterior term, then the small special loops with (k,l) as the INNER pair — branch-free as in the
+          // inside pass: rows / columns clamped to existing ones, enclosing pairs that do not exist dropped by
+          // a select, all weights fetched up front
+          const int rt = sfd_rtype(type);
+          const int sp1 = S[k - 1], sq1 = S[l + 1];
+          const int k1 = sfd_max(k - 1, 1), k2 = sfd_max(k - 2, 1), k3 = sfd_max(k - 3, 1), k4 = sfd_max(k - 4, 1);
+          const int l1 = sfd_min(l + 1, W), l2 = sfd_min(l + 2, W), l3 = sfd_min(l + 3, W), l4 = sfd_min(l + 4, W);
+          const bool e1 = inner, e2k = k - 2 >= 1, e3k = k - 3 >= 1, e4k = k - 4 >= 1;
+          const bool e2l = l + 2 <= W, e3l = l + 3 <= W, e4l = l + 4 <= W;
+          const int sk2 = S[k2], sk3 = S[k3], sl2 = S[l2], sl3 = S[l3];  // neighbours towards the loop
+          const double w00 = X->stack[PAIR(S[k1], S[l1])][rt];
+          const double w01 = X->stack[PAIR(S[k1], S[l2])][rt], w10 = X->stack[PAIR(S[k2], S[l1])][rt];
+          const double w11 = X->int11[PAIR(S[k2], S[l2])][rt][sp1][sq1];
+          const double w12 = X->int21[PAIR(S[k2], S[l3])][rt][sp1][sq1][sl2];  // u1 = 1, u2 = 2
+          const double w21 = X->int21[rt][PAIR(S[k3], S[l2])][sq1][sk2][sp1];  // u1 = 2, u2 = 1
+          const double w22 = X->int22[PAIR(S[k3], S[l3])][rt][sk2][sp1][sq1][sl2];
+          const double w23o = X->mismatch23I[rt][sq1][sp1];
+          const double w23 = X->mismatch23I[PAIR(S[k3], S[l4])][sk2][sl3], w32 = X->mismatch23I[PAIR(S[k4], S[l3])][sk3][sl2];
+          const double wI = X->mismatchI[rt][sq1][sp1];
+          const double wx = sfx_extloop(X, type, k > 1 ? sp1 : -1, l < W ? sq1 : -1);
           const double *dI3 = DERP(0, l + 3) + k;
           const int kr3 = r3 ? k - 3 : 1;  // row for speculative reads
           const double *fI = FAC + SF_PK_CODE(FWD[kr3]);
@@ -797,27 +869,6 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
             }
             H[0] = dI3[-3] * WN[0];
           }
-          const int type = OWN(k, l);
-          // exterior term, then the small special loops with (k,l) as the INNER pair — branch-free as in the
-          // inside pass: rows / columns clamped to existing ones, enclosing pairs that do not exist dropped by
-          // a select, all weights fetched up front
-          const int rt = sfd_rtype(type);
-          const int sp1 = S[k - 1], sq1 = S[l + 1];
-          const int k1 = sfd_max(k - 1, 1), k2 = sfd_max(k - 2, 1), k3 = sfd_max(k - 3, 1), k4 = sfd_max(k - 4, 1);
-          const int l1 = sfd_min(l + 1, W), l2 = sfd_min(l + 2, W), l3 = sfd_min(l + 3, W), l4 = sfd_min(l + 4, W);
-          const bool e1 = inner, e2k = k - 2 >= 1, e3k = k - 3 >= 1, e4k = k - 4 >= 1;
-          const bool e2l = l + 2 <= W, e3l = l + 3 <= W, e4l = l + 4 <= W;
-          const int sk2 = S[k2], sk3 = S[k3], sl2 = S[l2], sl3 = S[l3];  // neighbours towards the loop
-          const double w00 = X->stack[PAIR(S[k1], S[l1])][rt];
-          const double w01 = X->stack[PAIR(S[k1], S[l2])][rt], w10 = X->stack[PAIR(S[k2], S[l1])][rt];
-          const double w11 = X->int11[PAIR(S[k2], S[l2])][rt][sp1][sq1];
-          const double w12 = X->int21[PAIR(S[k2], S[l3])][rt][sp1][sq1][sl2];  // u1 = 1, u2 = 2
-          const double w21 = X->int21[rt][PAIR(S[k3], S[l2])][sq1][sk2][sp1];  // u1 = 2, u2 = 1
-          const double w22 = X->int22[PAIR(S[k3], S[l3])][rt][sk2][sp1][sq1][sl2];
-          const double w23o = X->mismatch23I[rt][sq1][sp1];
-          const double w23 = X->mismatch23I[PAIR(S[k3], S[l4])][sk2][sl3], w32 = X->mismatch23I[PAIR(S[k4], S[l3])][sk3][sl2];
-          const double wI = X->mismatchI[rt][sq1][sp1];
-          const double wx = sfx_extloop(X, type, k > 1 ? sp1 : -1, l < W ? sq1 : -1);
           const double q00 = QBC(k1, l1), q01 = QBC(k1, l2), q10 = QBC(k2, l1), q11 = QBC(k2, l2);
           const double q12 = QBC(k2, l3), q21 = QBC(k3, l2), q22 = QBC(k3, l3), q23 = QBC(k3, l4), q32 = QBC(k4, l3);
           double o = q5[k - 1] * q3[l + 1] * wx;
@@ -847,6 +898,7 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
           fc0 = FAC[1250 + SF_PK_ROW(BWD[l]) + SF_PK_CODE(FWD[k])];
           fc1 = R0c[k];
           const int sp1 = S[k - 1];
+          const double wst = mlblk1 ? sfx_mlstem(X, type, sp1, S[l + 1]) : 0.0;  // (device memory: in flight during the sums)
           const double *dB1 = DERP(2, l + 1) + k - 1;
           const double *qbA = QB + (k > 1 ? k - 2 : 0);  // row k-1 (row 1 for speculative reads)
           double gb = 0.0, gb2 = 0.0;
@@ -861,7 +913,7 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
           })
           ZP[VW + k] = (gb + gb2) * (type > 2 ? xTAU : 1.0);  // rtype(type) > 2 <=> type > 2
           // (wave-uniform: the late columns only)
-          ZP[8 * VW + k] = mlblk1 ? ml_part(mlsplit, W) * sfx_mlstem(X, type, sp1, S[l + 1]) : 0.0;
+          ZP[8 * VW + k] = mlblk1 ? ml_part(mlsplit, W) * wst : 0.0;
         }
 
       } else if (team == 2) {
@@ -899,10 +951,11 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
           const int type = OWN(k, l);
           typeC = type;
           const int sp1 = S[k - 1], sq1 = S[l + 1];
+          const double wst = sfx_mlstem(X, type, sp1, sq1);  // (device memory: in flight during the sums)
           double ms = 0.0;
           for (int a = 1; a <= sfd_min(k - 1, 5); a++) ms += MLB[a - 1] * R1c[k - a];
           ms += ml_part(6, mlsplit);
-          ZP[3 * VW + k] = ms * sfx_mlstem(X, type, sp1, sq1);
+          ZP[3 * VW + k] = ms * wst;
         }
       }
       __syncthreads();

@@ -68,9 +68,16 @@ STAMP_PATCHES = [
 # launch_pf waits for the kernel and appends the sums to $SF_STAMP_OUT (tools/dev/pf_stamp_report.py).
 PFL = "scanfold_amd/csrc/sf_pf_lds.hip.h"
 PFSTAMP_PATCHES = [
-    (PFL, "      if (team == 0) {\n        if (valid) {\n          const double *dI3 = DERP(0, l + 3) + k;",
+    (PFL, "    const bool ovl = SF_PFL_NZP * VW >= 900;\n",
+     "    const long long SFX0 = SFL ? (long long)clock64() : 0;\n    const bool ovl = SF_PFL_NZP * VW >= 900;\n"),
+    (PFL, "    __syncthreads();\n    if (tid >= 128) {\n      const int ht = tid - 128;",
+     "    __syncthreads();\n    if (SFL) atomicAdd(SFP + 48, (unsigned long long)(clock64() - SFX0));\n    if (tid >= 128) {\n      const int ht = tid - 128;"),
+    (PFL, "    __syncthreads();\n    if (!ovl) {\n      outside_tables(tid, SF_PFL_NT);",
+     "    if (SFL) atomicAdd(SFP + 49, (unsigned long long)(clock64() - SFX0));\n    __syncthreads();\n"
+     "    if (SFL) { atomicAdd(SFP + 50, (unsigned long long)(clock64() - SFX0)); atomicAdd(SFP + 51, 1ull); }\n    if (!ovl) {\n      outside_tables(tid, SF_PFL_NT);"),
+    (PFL, "      if (team == 0) {\n        if (valid) {\n          // (the cell's weights first:",
      "      if (SFL) atomicAdd(SFB + 0, (unsigned long long)(clock64() - SFT0));\n"
-     "      if (team == 0) {\n        if (valid) {\n          const double *dI3 = DERP(0, l + 3) + k;"),
+     "      if (team == 0) {\n        if (valid) {\n          // (the cell's weights first:"),
     (PFL, "    const bool nbL = SH && pos > 0, nbR = SH && pos + W < L;\n    __syncthreads();\n",
      "    const bool nbL = SH && pos > 0, nbR = SH && pos + W < L;\n    __syncthreads();\n"
      "    unsigned long long *const SFP = (unsigned long long *)((char *)status + 32768) + (tid >> 6) * 64;\n"

@@ -26,3 +26,8 @@ for w in range(8):
 ph = tot[0, 40:45] / folds
 names = ("reload / shift", "inside columns", "park + exterior + tables", "outside columns", "reductions + outputs")
 print("phases of a fold (cycles, wave 0): " + ", ".join("%s %.0f" % (n, v) for n, v in zip(names, ph)) + "; sum %.0f" % ph.sum())
+if tot[0, 51] > 0:
+    print("between the passes, cycles per fold from the end of the inside columns: exterior table built (barrier passed), own part done (waves 0-1: the sweeps; 2-7: park, tables, clearing), closing barrier passed")
+    for w in range(8):
+        n = max(tot[w, 51], 1)
+        print("  wave %d %10.0f %10.0f %10.0f" % (w, tot[w, 48] / n, tot[w, 49] / n, tot[w, 50] / n))

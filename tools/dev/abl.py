@@ -122,11 +122,10 @@ PFSTAMP_PATCHES = [
 VARIANTS = {
     "pfstamps": (PFSTAMP_PATCHES, []),
     # partition function, outside pass: team 1's share of team 3's multiloop sum, blocks of eight terms: (l - MLS0) / MLS1
-    "pfmls30_8": ([], ["-DSF_PFL_MLS0=30", "-DSF_PFL_MLS1=8", "-DSF_PFL_MLSX=16"]),
-    "pfmls20_10": ([], ["-DSF_PFL_MLS0=20", "-DSF_PFL_MLS1=10", "-DSF_PFL_MLSX=16"]),
-    "pfmls10_12": ([], ["-DSF_PFL_MLS0=10", "-DSF_PFL_MLS1=12", "-DSF_PFL_MLSX=16"]),
-    "pfmls40_8": ([], ["-DSF_PFL_MLS0=40", "-DSF_PFL_MLS1=8", "-DSF_PFL_MLSX=16"]),
-    "pfmlsx999": ([], ["-DSF_PFL_MLS0=30", "-DSF_PFL_MLS1=12", "-DSF_PFL_MLSX=999"]),
+    "pfmls30_8": ([], ["-DSF_PFL_MLS0=30", "-DSF_PFL_MLS1=8"]),
+    "pfmls20_10": ([], ["-DSF_PFL_MLS0=20", "-DSF_PFL_MLS1=10"]),
+    "pfmls10_12": ([], ["-DSF_PFL_MLS0=10", "-DSF_PFL_MLS1=12"]),
+    "pfmls40_8": ([], ["-DSF_PFL_MLS0=40", "-DSF_PFL_MLS1=8"]),
     "stamps": (STAMP_PATCHES, []),
     # name: (patches, flags)
     "head": ([], []),
@@ -137,18 +136,6 @@ VARIANTS = {
     "ntload": ([(FAST, "    for (int x = tidf; x < W; x += NT) S[x + 1] = sf_encode_nt(src[x]);", "    for (int x = tidf; x < W; x += NT) S[x + 1] = sf_encode_nt(__builtin_nontemporal_load(&src[x]));")], []),
     # (the scratch stride: "cgNNNN": ([(FAST, "#define SF_CG_ENTRIES(W) ((W) == 120 ? 7168 :", "#define SF_CG_ENTRIES(W) ((W) == 120 ? NNNN :")], []) —
     #  round 5 re-swept 6796 .. 8192 with tools/pmc_cmp.sh "WRITE_SIZE": 7168 still writes the least, 0.44 kB per fold against 0.78 .. 3.8)
-    # partition function: the column-offset lane table as scalar arithmetic (COFF of a wave-uniform column) instead of v_readlane
-    "pfcoff": ([("scanfold_amd/csrc/sf_pf_lds.hip.h", "      SF_LANE_TABLE(tcol, L, COFF(sfd_min(sfd_max(j - L, 5), W)));", "#define TCOL_IN(L_) COFF(sfd_min(sfd_max(j - (L_), 5), W))"),
-                ("scanfold_amd/csrc/sf_pf_lds.hip.h", "      SF_LANE_TABLE(tcol, L, l + L <= W ? COFF(l + L) : ZOFF);", "#define TCOL_OUT(L_) (l + (L_) <= W ? COFF(l + (L_)) : ZOFF)"),
-                ("scanfold_amd/csrc/sf_pf_lds.hip.h", '            qa[t] = qbA[SF_LANE_GET(tcol, u - 1)]; fa[t] = fI[SF_PK_ROW(SF_LANE_GET(tpk, u - 1))];\n            da[t] = dI3[u - 1]; wa[t] = WN[u - 4];', '            qa[t] = qbA[TCOL_IN(u - 1)]; fa[t] = fI[SF_PK_ROW(SF_LANE_GET(tpk, u - 1))];\n            da[t] = dI3[u - 1]; wa[t] = WN[u - 4];'),
-                ("scanfold_amd/csrc/sf_pf_lds.hip.h", '            const double a = qbA[SF_LANE_GET(tcol, 4)] * fI[SF_PK_ROW(SF_LANE_GET(tpk, 4))];\n            H[1] = ((umax >= 5 ? a : 0.0) + dI3[4]) * WN[1];', '            const double a = qbA[TCOL_IN(4)] * fI[SF_PK_ROW(SF_LANE_GET(tpk, 4))];\n            H[1] = ((umax >= 5 ? a : 0.0) + dI3[4]) * WN[1];'),
-                ("scanfold_amd/csrc/sf_pf_lds.hip.h", '            qa[t] = qbA[SF_LANE_GET(tcol, u_ + 1)]; da[t] = dB1[u_]; wa[t] = WB[u_]; fa[t] = 0.0;', '            qa[t] = qbA[TCOL_IN(u_ + 1)]; da[t] = dB1[u_]; wa[t] = WB[u_]; fa[t] = 0.0;'),
-                ("scanfold_amd/csrc/sf_pf_lds.hip.h", '            qa[t] = qbA[SF_LANE_GET(tcol, u_)]; fa[t] = f1N[SF_PK_ROW(SF_LANE_GET(tpk, u_))];\n            da[t] = d1N2[u_]; wa[t] = WIL1N[u_];', '            qa[t] = qbA[TCOL_IN(u_)]; fa[t] = f1N[SF_PK_ROW(SF_LANE_GET(tpk, u_))];\n            da[t] = d1N2[u_]; wa[t] = WIL1N[u_];'),
-                ("scanfold_amd/csrc/sf_pf_lds.hip.h", '              qa[t] = qbA[SF_LANE_GET(tcol, u - 1)]; fa[t] = fI[SF_PK_ROW(SF_LANE_GET(tpk, u - 1))];', '              qa[t] = qbA[TCOL_OUT(u - 1)]; fa[t] = fI[SF_PK_ROW(SF_LANE_GET(tpk, u - 1))];'),
-                ("scanfold_amd/csrc/sf_pf_lds.hip.h", '              const double a = qbA[SF_LANE_GET(tcol, 4)] * fI[SF_PK_ROW(SF_LANE_GET(tpk, 4))];\n              const double e1 = r3 ? a : 0.0;', '              const double a = qbA[TCOL_OUT(4)] * fI[SF_PK_ROW(SF_LANE_GET(tpk, 4))];\n              const double e1 = r3 ? a : 0.0;'),
-                ("scanfold_amd/csrc/sf_pf_lds.hip.h", '            qa[t] = qbA[SF_LANE_GET(tcol, u_ + 1)]; da[t] = dB1[-u_]; wa[t] = WB[u_]; fa[t] = 0.0;', '            qa[t] = qbA[TCOL_OUT(u_ + 1)]; da[t] = dB1[-u_]; wa[t] = WB[u_]; fa[t] = 0.0;'),
-                ("scanfold_amd/csrc/sf_pf_lds.hip.h", '            qa[t] = qbA[SF_LANE_GET(tcol, u_)]; fa[t] = f1N[SF_PK_ROW(SF_LANE_GET(tpk, u_))];\n            da[t] = d1N2[-u_]; wa[t] = WIL1N[u_];', '            qa[t] = qbA[TCOL_OUT(u_)]; fa[t] = f1N[SF_PK_ROW(SF_LANE_GET(tpk, u_))];\n            da[t] = d1N2[-u_]; wa[t] = WIL1N[u_];'),
-               ], []),
     "tiny8": ([], ["-DSF_FAST_TINY_D0=8"]), "tiny12": ([], ["-DSF_FAST_TINY_D0=12"]),
     "pb4": ([], ["-DSF_UNP_PB=4"]),
     "pb6": ([], ["-DSF_UNP_PB=6"]), "pb12": ([], ["-DSF_UNP_PB=12"]),

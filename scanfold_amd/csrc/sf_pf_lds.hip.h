@@ -585,58 +585,85 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
       using I0 = std::integral_constant<int, 0>;
       using I1 = std::integral_constant<int, 1>;
       double qr[NQ] = {0.0, 0.0};  // q5[lane + 64 h] (forward), q3[lane + 64 h + 1] (backward)
+      // (a step's table values are fetched during the step before: the reads do not depend on the walk's sums)
       if (fwd) {
         int cj[NQ];  // COFF(j) - 1 of this lane's columns
 #pragma unroll
         for (int q = 0; q < NQ; q++) cj[q] = COFF(sfd_max(sfd_min(lane + 64 * q + 1, W), 5)) - 1;
+        const int codeBp = codeB[0] | (codeB[1] << 16);  // both rows of a lane in one register: one v_readlane per step
         double qprev = 1.0;  // q5[i-1] while row i is processed
         if (lane == 0) qr[0] = 1.0;
-        auto step = [&](const int i, auto OHH, auto XHH, auto CHH, auto Q0) {
-          constexpr int OH = decltype(OHH)::value, XH = decltype(XHH)::value, CH = decltype(CHH)::value, QLO = decltype(Q0)::value;
+        double qv[NQ] = {0.0, 0.0}, ev[NQ] = {0.0, 0.0};
+        auto fetch = [&](const int i, auto Q0) {  // qb[i, j] (0 where the cell does not exist) and the weight of (i, j) for this lane's columns
+          constexpr int QLO = decltype(Q0)::value;
+          const int cb = (sf_lane_read_i32(codeBp, (i - 1) & 63) >> (((i - 1) >> 6) << 4)) & 0xffff;
+#pragma unroll
+          for (int q = QLO; q < NQ; q++) {
+            const int j = lane + 64 * q + 1;
+            const bool ok = j <= W && i + SFD_TURN + 1 <= j && j - i <= maxd;
+            const double qb = QB[cj[q] + sfd_min(i, W - SFD_TURN - 1)];
+            qv[q] = ok ? qb : 0.0;
+            ev[q] = EXT[codeF[q] + cb];
+          }
+        };
+        auto step = [&](const int i, auto OHH, auto XHH, auto Q0) {
+          constexpr int OH = decltype(OHH)::value, XH = decltype(XHH)::value, QLO = decltype(Q0)::value;
           if (i >= 2) {
             qprev += sf_lane_read_f64(P[OH], (i - 2) & 63);
             qr[XH] = (lane == ((i - 1) & 63)) ? qprev : qr[XH];
           }
           if (i > W - SFD_TURN - 1) return;
-          const int cb = sf_lane_read_i32(codeB[CH], (i - 1) & 63);
+          double t[NQ];
 #pragma unroll
-          for (int q = QLO; q < NQ; q++) {
-            const int j = lane + 64 * q + 1;
-            const bool ok = j <= W && i + SFD_TURN + 1 <= j && j - i <= maxd;
-            const double qb = ok ? QB[cj[q] + i] : 0.0;
-            P[q] += qprev * qb * EXT[codeF[q] + cb];
-          }
+          for (int q = QLO; q < NQ; q++) t[q] = qprev * qv[q] * ev[q];
+          if (i + 1 <= W - SFD_TURN - 1) fetch(i + 1, Q0);
+#pragma unroll
+          for (int q = QLO; q < NQ; q++) P[q] += t[q];
         };
-        for (int i = 1; i <= sfd_min(W, 64); i++) step(i, I0{}, I0{}, I0{}, I0{});
-        if (W >= 65) step(65, I0{}, I1{}, I1{}, I1{});
-        for (int i = 66; i <= W; i++) step(i, I1{}, I1{}, I1{}, I1{});
+        fetch(1, I0{});
+        for (int i = 1; i <= sfd_min(W, 64); i++) step(i, I0{}, I0{}, I0{});
+        if (W >= 65) step(65, I0{}, I1{}, I1{});
+        for (int i = 66; i <= W; i++) step(i, I1{}, I1{}, I1{});
         qprev += owner_sum(W);
 #pragma unroll
         for (int q = 0; q < NQ; q++)
           if (lane + 64 * q < W) q5[lane + 64 * q] = qr[q];
         if (lane == 0) q5[W] = qprev;
       } else {
+        const int codeFp = (codeF[0] / 30) | ((codeF[1] / 30) << 16);
         double qnext = 1.0;  // q3[j+1] while column j is processed
-        auto step = [&](const int j, auto OHH, auto CHH, auto Q1) {
-          constexpr int OH = decltype(OHH)::value, CH = decltype(CHH)::value, QHI = decltype(Q1)::value;
-          if (j < W) {
-            qnext += sf_lane_read_f64(P[OH], j & 63);
-            qr[OH] = (lane == (j & 63)) ? qnext : qr[OH];
-          }
-          if (j < SFD_TURN + 2) return;
-          const int cf = sf_lane_read_i32(codeF[CH], (j - 1) & 63);
+        double qv[NQ] = {0.0, 0.0}, ev[NQ] = {0.0, 0.0};
+        auto fetch = [&](const int j, auto Q1) {
+          constexpr int QHI = decltype(Q1)::value;
+          const int cf = ((sf_lane_read_i32(codeFp, (j - 1) & 63) >> (((j - 1) >> 6) << 4)) & 0xffff) * 30;
           const int cq = COFF(sfd_max(j, 5)) - 1;
 #pragma unroll
           for (int q = 0; q <= QHI; q++) {
             const int i = lane + 64 * q + 1;
             const bool ok = i + SFD_TURN + 1 <= j && j - i <= maxd;
-            const double qb = ok ? QB[cq + i] : 0.0;
-            P[q] += qb * EXT[cf + codeB[q]] * qnext;
+            const double qb = QB[cq + sfd_min(i, W)];
+            qv[q] = ok ? qb : 0.0;
+            ev[q] = EXT[cf + codeB[q]];
           }
         };
-        for (int j = W; j >= 65; j--) step(j, I1{}, I1{}, I1{});
-        if (W >= 64) step(64, I1{}, I0{}, I0{});
-        for (int j = sfd_min(W, 63); j >= 1; j--) step(j, I0{}, I0{}, I0{});
+        auto step = [&](const int j, auto OHH, auto Q1) {
+          constexpr int OH = decltype(OHH)::value, QHI = decltype(Q1)::value;
+          if (j < W) {
+            qnext += sf_lane_read_f64(P[OH], j & 63);
+            qr[OH] = (lane == (j & 63)) ? qnext : qr[OH];
+          }
+          if (j < SFD_TURN + 2) return;
+          double t[NQ];
+#pragma unroll
+          for (int q = 0; q <= QHI; q++) t[q] = qv[q] * ev[q] * qnext;
+          if (j - 1 >= SFD_TURN + 2) fetch(j - 1, Q1);
+#pragma unroll
+          for (int q = 0; q <= QHI; q++) P[q] += t[q];
+        };
+        fetch(W, I1{});
+        for (int j = W; j >= 65; j--) step(j, I1{}, I1{});
+        if (W >= 64) step(64, I1{}, I0{});
+        for (int j = sfd_min(W, 63); j >= 1; j--) step(j, I0{}, I0{});
         qnext += owner_sum(1);
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
@@ -659,6 +686,11 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
     for (int u = 0; u < 27; u++) H[u] = 0.0;
     double mbd = 0.0, cd = 0.0;
     double racc[2] = {0.0, 0.0};  // the block sums of R1 for this team's two columns of the block, row kf
+    int tbw[2];  // lane table: byte offset of the weight-table row of column m = lane + 64 h + 1 (its nucleotides: wave-uniform per term)
+#pragma unroll
+    for (int h = 0; h < 2; h++) tbw[h] = SF_PK_ROW(BWD[sfd_min((tid & 63) + 64 * h + 1, W)]) * (int)sizeof(double);
+    SF_LANE_TABLE_PIN(tbw[0]);
+    SF_LANE_TABLE_PIN(tbw[1]);
     // lane tables, entry L: column min(l+L, W).  Those of column l-1 are fetched while column l's results are written (after the
     // first barrier): a column does not start with an LDS round trip every wave waits for
     SF_LANE_TABLE_DECL(tpk);
@@ -730,27 +762,22 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
         racc[0] = racc[1] = 0.0;
         const double *fW = FAC + 1250 + SF_PK_CODE(FWD[sfd_min(kr, W)]);
         const double *qp = QB + kr - 1;
-        // four columns m per trip, their reads issued together; the neighbour codes — the address of a term's weight — are fetched
-        // one trip ahead (one m per trip was two dependent LDS round trips per term).  The columns m-1 < 64 and >= 64 as two
-        // loops: which half of the rows of qm a term reads is then a compile-time constant (as a test per term it compiled to ~30
-        // branches per trip).
+        // four columns m per trip, their reads issued together (one m per trip was two dependent LDS round trips per term).  The
+        // columns m-1 < 64 and >= 64 as two loops: which half of the rows of qm a term reads is then a compile-time constant (as a
+        // test per term it compiled to ~30 branches per trip).
         auto half = [&](auto HH, const int mlo, const int mhi) {
           constexpr int h = decltype(HH)::value;
           if (mlo > mhi) return;
-          int bw[4];
-#pragma unroll
-          for (int t = 0; t < 4; t++) bw[t] = BWD[sfd_min(mlo + t, mhi)];
-          // (whole trips without any clamping, the last — partial — one with)
+          // (whole trips without any clamping, the last — partial — one with; the row of a term's weight in its table comes from
+          // a lane table, tbw: as an LDS read it was a round trip ahead of the read of the weight)
           int m = mlo, coff = COFF(mlo);
           for (; m + 3 <= mhi; m += 4) {
             double q[4], f[4];
-            int bn[4];
 #pragma unroll
             for (int t = 0; t < 4; t++) {
               q[t] = qp[coff];
               coff += m + t - 4;  // COFF(x+1) - COFF(x) = x - 4
-              f[t] = fW[SF_PK_ROW(bw[t])];
-              bn[t] = BWD[m + 4 + t];  // (up to three entries past mhi <= W: inside the table, W+2 entries, or the array behind it; not used)
+              f[t] = *(const double *)((const char *)fW + sf_lane_read_i32(tbw[h], m + t - 1 - 64 * h));
             }
             SF_SCHED_FENCE();
 #pragma unroll
@@ -759,7 +786,6 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
               const int cq = m + t - 1 - 64 * h;
               racc[0] += w * sf_lane_read_f64(g[0][h], cq);
               racc[1] += w * sf_lane_read_f64(g[1][h], cq);
-              bw[t] = bn[t];
             }
           }
           if (m <= mhi) {
@@ -768,7 +794,7 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
             for (int t = 0; t < 4; t++) {
               const int mt = sfd_min(m + t, mhi);
               q[t] = qp[COFF(mt)];
-              f[t] = fW[SF_PK_ROW(t == 0 ? bw[0] : BWD[mt])];
+              f[t] = *(const double *)((const char *)fW + sf_lane_read_i32(tbw[h], mt - 1 - 64 * h));
             }
 #pragma unroll
             for (int t = 0; t < 4; t++) {

@@ -46,6 +46,9 @@
 #ifndef SF_PFL_RB
 #define SF_PFL_RB 8
 #endif
+#ifndef SF_PFL_LSP
+#define SF_PFL_LSP 64  // outside pass: team 1 takes six of team 0's special loops in the columns l <= LSP
+#endif
 #ifndef SF_PFL_MLS0
 #define SF_PFL_MLS0 30
 #define SF_PFL_MLS1 12
@@ -845,6 +848,31 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
         }
         return ms + ms2;
       };
+      // The special loops 1x1 .. 2x3 with (k,l) as the inner pair (six of the nine candidates): team 0's in the late columns (handing
+      // them to team 2 there: measured, no gain), team 1's in the early ones (l <= LSP), where team 0's own role is the longest of the four (per-team stamps: 5.5 against 3.2 - 4.7 k
+      // cycles per column) and team 1 has neither long rows nor a share of the multiloop sums.
+      const bool spx = l <= SF_PFL_LSP;
+      auto sp_tail = [&](const int type) -> double {
+        const int rt = sfd_rtype(type);
+        const int sp1 = S[k - 1], sq1 = S[l + 1];
+        const int k2 = sfd_max(k - 2, 1), k3 = sfd_max(k - 3, 1), k4 = sfd_max(k - 4, 1);
+        const int l2 = sfd_min(l + 2, W), l3 = sfd_min(l + 3, W), l4 = sfd_min(l + 4, W);
+        const bool e2k = k - 2 >= 1, e3k = k - 3 >= 1, e4k = k - 4 >= 1;
+        const bool e2l = l + 2 <= W, e3l = l + 3 <= W, e4l = l + 4 <= W;
+        const int sk2 = S[k2], sk3 = S[k3], sl2 = S[l2], sl3 = S[l3];  // neighbours towards the loop
+        const double w11 = X->int11[PAIR(S[k2], S[l2])][rt][sp1][sq1];
+        const double w12 = X->int21[PAIR(S[k2], S[l3])][rt][sp1][sq1][sl2];  // u1 = 1, u2 = 2
+        const double w21 = X->int21[rt][PAIR(S[k3], S[l2])][sq1][sk2][sp1];  // u1 = 2, u2 = 1
+        const double w22 = X->int22[PAIR(S[k3], S[l3])][rt][sk2][sp1][sq1][sl2];
+        const double w23o = X->mismatch23I[rt][sq1][sp1];
+        const double w23 = X->mismatch23I[PAIR(S[k3], S[l4])][sk2][sl3], w32 = X->mismatch23I[PAIR(S[k4], S[l3])][sk3][sl2];
+        const double q11 = QBC(k2, l2), q12 = QBC(k2, l3), q21 = QBC(k3, l2), q22 = QBC(k3, l3), q23 = QBC(k3, l4), q32 = QBC(k4, l3);
+        double t = ((e2k && e2l) ? q11 : 0.0) * w11;
+        t += ((e2k && e3l) ? q12 : 0.0) * w12 + ((e3k && e2l) ? q21 : 0.0) * w21;
+        t += ((e3k && e3l) ? q22 : 0.0) * w22;
+        t += (WIL[5] * WN[1] * w23o) * (((e3k && e4l) ? q23 : 0.0) * w23 + ((e4k && e3l) ? q32 : 0.0) * w32);
+        return t;
+      };
       if (team == 0) {
         if (valid) {
           // (the cell's weights first: a dozen gathers from device memory, in flight while the recurrence below runs — they used to
@@ -855,19 +883,12 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
           // a select, all weights fetched up front
           const int rt = sfd_rtype(type);
           const int sp1 = S[k - 1], sq1 = S[l + 1];
-          const int k1 = sfd_max(k - 1, 1), k2 = sfd_max(k - 2, 1), k3 = sfd_max(k - 3, 1), k4 = sfd_max(k - 4, 1);
-          const int l1 = sfd_min(l + 1, W), l2 = sfd_min(l + 2, W), l3 = sfd_min(l + 3, W), l4 = sfd_min(l + 4, W);
-          const bool e1 = inner, e2k = k - 2 >= 1, e3k = k - 3 >= 1, e4k = k - 4 >= 1;
-          const bool e2l = l + 2 <= W, e3l = l + 3 <= W, e4l = l + 4 <= W;
-          const int sk2 = S[k2], sk3 = S[k3], sl2 = S[l2], sl3 = S[l3];  // neighbours towards the loop
+          const int k1 = sfd_max(k - 1, 1), k2 = sfd_max(k - 2, 1);
+          const int l1 = sfd_min(l + 1, W), l2 = sfd_min(l + 2, W);
+          const bool e1 = inner, e2k = k - 2 >= 1, e2l = l + 2 <= W;
           const double w00 = X->stack[PAIR(S[k1], S[l1])][rt];
           const double w01 = X->stack[PAIR(S[k1], S[l2])][rt], w10 = X->stack[PAIR(S[k2], S[l1])][rt];
-          const double w11 = X->int11[PAIR(S[k2], S[l2])][rt][sp1][sq1];
-          const double w12 = X->int21[PAIR(S[k2], S[l3])][rt][sp1][sq1][sl2];  // u1 = 1, u2 = 2
-          const double w21 = X->int21[rt][PAIR(S[k3], S[l2])][sq1][sk2][sp1];  // u1 = 2, u2 = 1
-          const double w22 = X->int22[PAIR(S[k3], S[l3])][rt][sk2][sp1][sq1][sl2];
-          const double w23o = X->mismatch23I[rt][sq1][sp1];
-          const double w23 = X->mismatch23I[PAIR(S[k3], S[l4])][sk2][sl3], w32 = X->mismatch23I[PAIR(S[k4], S[l3])][sk3][sl2];
+          const double tail0 = spx ? 0.0 : sp_tail(type);
           const double wI = X->mismatchI[rt][sq1][sp1];
           const double wx = sfx_extloop(X, type, k > 1 ? sp1 : -1, l < W ? sq1 : -1);
           const double *dI3 = DERP(0, l + 3) + k;
@@ -895,16 +916,12 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
             }
             H[0] = dI3[-3] * WN[0];
           }
-          const double q00 = QBC(k1, l1), q01 = QBC(k1, l2), q10 = QBC(k2, l1), q11 = QBC(k2, l2);
-          const double q12 = QBC(k2, l3), q21 = QBC(k3, l2), q22 = QBC(k3, l3), q23 = QBC(k3, l4), q32 = QBC(k4, l3);
+          const double q00 = QBC(k1, l1), q01 = QBC(k1, l2), q10 = QBC(k2, l1);
           double o = q5[k - 1] * q3[l + 1] * wx;
           {
             double oi = q00 * w00;
             oi += ((e2l ? q01 : 0.0) * w01 + (e2k ? q10 : 0.0) * w10) * WB[1];
-            oi += ((e2k && e2l) ? q11 : 0.0) * w11;
-            oi += ((e2k && e3l) ? q12 : 0.0) * w12 + ((e3k && e2l) ? q21 : 0.0) * w21;
-            oi += ((e3k && e3l) ? q22 : 0.0) * w22;
-            oi += (WIL[5] * WN[1] * w23o) * (((e3k && e4l) ? q23 : 0.0) * w23 + ((e4k && e3l) ? q32 : 0.0) * w32);
+            oi += tail0;
             double gg = 0.0, gg2 = 0.0;
 #pragma unroll
             for (int u = 6; u <= 30; u += 2) {
@@ -925,6 +942,7 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
           fc1 = R0c[k];
           const int sp1 = S[k - 1];
           const double wst = mlblk1 ? sfx_mlstem(X, type, sp1, S[l + 1]) : 0.0;  // (device memory: in flight during the sums)
+          const double tail1 = spx ? sp_tail(type) : 0.0;
           const double *dB1 = DERP(2, l + 1) + k - 1;
           const double *qbA = QB + (k > 1 ? k - 2 : 0);  // row k-1 (row 1 for speculative reads)
           double gb = 0.0, gb2 = 0.0;
@@ -937,7 +955,7 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
             const double tt = (ab + da[t]) * wa[t];  // u1 = 0, u2 = 0
             if (u_ & 1) gb2 += tt; else gb += tt;
           })
-          ZP[VW + k] = (gb + gb2) * (type > 2 ? xTAU : 1.0);  // rtype(type) > 2 <=> type > 2
+          ZP[VW + k] = (gb + gb2) * (type > 2 ? xTAU : 1.0) + tail1;  // rtype(type) > 2 <=> type > 2
           // (wave-uniform: the late columns only)
           ZP[8 * VW + k] = mlblk1 ? ml_part(mlsplit, W) * wst : 0.0;
         }

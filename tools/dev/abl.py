@@ -122,6 +122,8 @@ PFSTAMP_PATCHES = [
 VARIANTS = {
     "pfstamps": (PFSTAMP_PATCHES, []),
     # partition function, outside pass: team 1's share of team 3's multiloop sum, blocks of eight terms: (l - MLS0) / MLS1
+    # partition function, outside pass: the columns in which team 1 takes six of team 0's special loops
+    "pflsp0": ([], ["-DSF_PFL_LSP=0"]), "pflsp40": ([], ["-DSF_PFL_LSP=40"]), "pflsp90": ([], ["-DSF_PFL_LSP=90"]),
     "pfmls30_8": ([], ["-DSF_PFL_MLS0=30", "-DSF_PFL_MLS1=8"]),
     "pfmls20_10": ([], ["-DSF_PFL_MLS0=20", "-DSF_PFL_MLS1=10"]),
     "pfmls10_12": ([], ["-DSF_PFL_MLS0=10", "-DSF_PFL_MLS1=12"]),

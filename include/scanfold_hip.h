@@ -96,7 +96,7 @@ int sf_pf_batch(const uint8_t *seqs, int n, int W, double *ensemble_dG, double *
  *                  partition function call.
  * Outputs as sf_mfe_trace_batch / sf_pf_batch; any may be NULL.  flags: SF_FOLD_NO_PF, SF_FOLD_NO_MFE.
  * These folds run on the kernels of the hot path with the constraint applied where a cell's pair type is made: the MFE on the
- * LDS kernel (W <= 250); the partition function on the LDS kernel (W <= 120 ... 128, what fits one CU) and above that on the
+ * LDS kernel (W <= 250); the partition function on the LDS kernel (W <= 120: what fits the LDS of one CU) and above that on the
  * device-table kernel sf_pf_fast_kernel<..., HC> (W <= 250).  Wider windows, and any batch that holds a bracket pair of
  * non-complementary bases (type 7), go to the general int32 / FP64 kernels; same results either way.  Shuffles are folded
  * unconstrained, as upstream. */

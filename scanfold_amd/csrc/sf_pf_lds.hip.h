@@ -1,4 +1,4 @@
-// sf_pf_lds.hip.h — McCaskill partition function with every table resident in LDS (W <= ~120).
+// sf_pf_lds.hip.h — McCaskill partition function with every table resident in LDS (W <= 120).
 //
 // Same mathematics and outputs as sf_pf_fast.hip.h / sf_pf.hip.h; replaces fc.pf() / fc.centroid() /
 // fc.mean_bp_distance() for the native windows (ScanFold-Scan.py:383-389).  What is different is the order of
@@ -19,9 +19,13 @@
 //      team 0  generic interior-loop sums (the register recurrence), small special loops, hairpin / exterior
 //      team 1  bulges                      team 2  1xn loops, then the cell's final sum and all table writes
 //      team 3  multiloop sum of the cell (inside: closing term, plus the hairpin; outside: stem term)
-//      teams 1 and 2 also share the second O(W) sum of a column (inside: qm of column j-1; outside: R1 of
-//      column l-1), half of its range each — that balances the four roles to within ~20 %
-//    partial sums meet in LDS; two barriers per column.
+//      inside, teams 0 and 1 also share the second O(W) sum of a column (qm of column j-1).  Outside, that second sum (R1 of
+//      column l-1) is a matrix product and evaluated for eight columns at a time (r1_block below: a fixed row per thread, two of
+//      the block's columns per team, the rows of qm read across lanes); team 1 takes the tail of team 3's multiloop sums in the
+//      late columns and six of team 0's special loops in the early ones (shares from per-team cycle stamps, tools/dev/abl.py
+//      "pfstamps")
+//    partial sums meet in LDS; two barriers per column.  Between the passes two waves walk the exterior sums while the other six
+//    park the inside state (shared runs) and build the outside pass's tables.
 //  * qb/ob are stored column-major (a column's rows are consecutive: the lanes of a wave read consecutive
 //    doubles for every interior-loop candidate), qm diagonal-major (multiloop sums run over the offset from the
 //    thread's own row).  Interior-loop candidates come in two families:

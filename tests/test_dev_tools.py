@@ -43,4 +43,4 @@ def test_run_round_script_parses_and_knows_its_modes():
     sh = os.path.join(ROOT, "tools", "run_round.sh")
     assert subprocess.run(["bash", "-n", sh]).returncode == 0
     p = subprocess.run(["bash", sh, "nonsense", "r00"], capture_output=True, text=True)
-    assert p.returncode == 2 and "measure|final|collect" in p.stdout
+    assert p.returncode == 2 and "measure|final|sweeps|collect" in p.stdout

@@ -7,6 +7,8 @@
 #        warm-up launch, so that the counters are the timed kernel's — summarised in gpurun_out/RR_final/C/[C_]mfe_counters.json
 #   bash tools/run_round.sh final RR       the GPU test suite, `measure` for cfg3 and cfg5, the secondary workloads of SURVEY 8d
 #        (mononucleotide shuffles; viral-like input), the one-GPU shard-step estimate -> gpurun_out/RR_final/
+#   bash tools/run_round.sh sweeps RR      every width 16..256 against the oracle (plain, constrained), shared against stand-alone inside
+#        tables, the parity campaign, the partition-function time inside a scan at W = 120 / 100 / 60 -> gpurun_out/RR_final/sweeps/
 #   bash tools/run_round.sh collect RR     copies what `final` left under gpurun_out/RR_final into profiles/RR/ (the tracked copies;
 #        bench.py --no-live-counters reads profiles/RR/*mfe_counters.json)
 # RR = r05, r06, ...
@@ -90,6 +92,15 @@ j=json.load(open('$S/$f')); print('$f', round(j['value'],1), j['verified_mismatc
   tail -7 $S/shard_step_cfg3.txt
 }
 
+sweeps() {
+  cd $R; mkdir -p $S/sweeps
+  timeout 900 python3 tools/gpu_wsweep_full.py > $S/sweeps/wsweep_full.txt 2>&1; tail -1 $S/sweeps/wsweep_full.txt
+  timeout 600 python3 tools/gpu_wsweep_constrained.py > $S/sweeps/wsweep_constrained.txt 2>&1; tail -1 $S/sweeps/wsweep_constrained.txt
+  timeout 600 python3 tools/gpu_share_check.py > $S/sweeps/share_check.txt 2>&1; tail -1 $S/sweeps/share_check.txt
+  timeout 900 python3 tools/gpu_parity_campaign.py > $S/sweeps/parity_campaign.txt 2>&1; tail -1 $S/sweeps/parity_campaign.txt
+  for W in 120 100 60; do timeout 600 python3 tools/gpu_pf_scan_cmp.py $W 1 2>&1 | grep -v amdgpu.ids; done | tee $S/sweeps/pf_scan_times.txt
+}
+
 collect() {
   local D=$R/profiles/$RR; mkdir -p $D
   newest() { ls -t $1 2>/dev/null | head -1; }
@@ -107,12 +118,14 @@ collect() {
   cp $S/bench_viral.json $D/secondary_bench_viral.json
   cp $S/gpu_tests.log $D/gpu_tests.log
   cp $S/shard_step_cfg3.txt $S/shard_step_cfg5_first_4096_windows.txt $D/ 2>/dev/null
+  cp $S/sweeps/*.txt $D/ 2>/dev/null
   ls $D
 }
 
 case "$MODE" in
   measure) measure "$@" ;;
   final) final ;;
+  sweeps) sweeps ;;
   collect) collect ;;
-  *) echo "usage: bash tools/run_round.sh measure|final|collect RR [cfg3|cfg5] [bench flags]"; exit 2 ;;
+  *) echo "usage: bash tools/run_round.sh measure|final|sweeps|collect RR [cfg3|cfg5] [bench flags]"; exit 2 ;;
 esac

@@ -80,13 +80,22 @@
 #define SF_LANE_TABLE_PIN(name) asm volatile("" : "+v"(name))
 #define SF_LANE_GET(name, idx) __builtin_amdgcn_readlane(name, idx)
 #endif
-// Sizes UHI down to ULO in batches of NB: LOAD (fills qa[t], fa[t], da[t], wa[t] for size u) for a whole batch, then USE for
-// the same sizes in the same order.  The arithmetic and its order are those of the plain loop; the fences (SF_SCHED_FENCE, sf_launch.h) keep the
-// compiler from re-interleaving the two phases (it then waits for nearly every LDS read where it is issued).
-#define SF_PFL_BATCHES(UHI, ULO, NB, LOAD, USE)                                   \
+// Sizes UHI down to ULO in batches of NB: PRE (fills ca[t], pa[t]: the lane-table entries of size u — a v_readlane each, whose
+// scalar result the vector ALU may not use in the next instruction: read for the whole batch first, they need no hazard no-ops),
+// LOAD (fills qa[t], fa[t], da[t], wa[t] for size u) for a whole batch, then USE for the same sizes in the same order.  The arithmetic
+// and its order are those of the plain loop; the fences (SF_SCHED_FENCE, sf_launch.h) keep the compiler from re-interleaving the
+// phases (it then waits for nearly every LDS read where it is issued).
+#define SF_PFL_BATCHES(UHI, ULO, NB, PRE, LOAD, USE)                              \
   _Pragma("unroll") for (int ub_ = (UHI); ub_ >= (ULO); ub_ -= (NB)) {            \
     double qa[NB], fa[NB], da[NB], wa[NB];                                        \
-    (void)fa;                                                                     \
+    int ca[NB], pa[NB];                                                           \
+    (void)fa; (void)pa; (void)ca;                                                           \
+    SF_SCHED_FENCE();                                                             \
+    _Pragma("unroll") for (int t = 0; t < (NB); t++) {                            \
+      const int u = ub_ - t;                                                      \
+      ca[t] = 0; pa[t] = 0;                                                       \
+      if (u >= (ULO)) PRE                                                         \
+    }                                                                             \
     SF_SCHED_FENCE();                                                             \
     _Pragma("unroll") for (int t = 0; t < (NB); t++) {                            \
       const int u = ub_ - t;                                                      \
@@ -380,8 +389,8 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
           // Straight-line: family-A values are loaded speculatively (column clamped to an existing one) and
           // dropped by a select when the inner span would be < TURN+1; family-B values are 0 there by
           // themselves.  Sizes beyond umax therefore stay exactly 0 and need no separate bookkeeping.
-          SF_PFL_BATCHES(30, 6, 9, {
-            qa[t] = qbA[SF_LANE_GET(tcol, u - 1)]; fa[t] = fI[SF_PK_ROW(SF_LANE_GET(tpk, u - 1))];
+          SF_PFL_BATCHES(30, 6, 9, { ca[t] = SF_LANE_GET(tcol, u - 1); pa[t] = SF_PK_ROW(SF_LANE_GET(tpk, u - 1)); }, {
+            qa[t] = qbA[ca[t]]; fa[t] = fI[pa[t]];
             da[t] = dI3[u - 1]; wa[t] = WN[u - 4];
           }, {
             const double a = qa[t] * fa[t];
@@ -433,12 +442,12 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
           const double *dB1 = DERP(2, j - 1) + i + 1;
           const double *qbA = QB + i;  // row i+1
           double gb = 0.0, gb2 = 0.0;
-          SF_PFL_BATCHES(30, 2, 10, {
+          SF_PFL_BATCHES(30, 2, 10, { ca[t] = SF_LANE_GET(tcol, 33 - u); pa[t] = SF_PK_NT(SF_LANE_GET(tpk, 33 - u)); }, {
             const int u_ = 32 - u;  // ascending sizes 2..30, as the sums were always accumulated
-            qa[t] = qbA[SF_LANE_GET(tcol, u_ + 1)]; da[t] = dB1[u_]; wa[t] = WB[u_]; fa[t] = 0.0;
+            qa[t] = qbA[ca[t]]; da[t] = dB1[u_]; wa[t] = WB[u_]; fa[t] = 0.0;
           }, {
             const int u_ = 32 - u;
-            const double ta_ = (sp * SF_PK_NT(SF_LANE_GET(tpk, u_ + 1)) == 6) ? 1.0 : xTAU;  // C-G / G-C: no terminal penalty
+            const double ta_ = (sp * pa[t] == 6) ? 1.0 : xTAU;  // C-G / G-C: no terminal penalty
             const double ab = qa[t] * ta_;
             const double tt = ((u_ <= umax ? ab : 0.0) + da[t]) * wa[t];
             if (u_ & 1) gb2 += tt; else gb += tt;
@@ -456,9 +465,9 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
           const double *f1N = FAC + 625 + SF_PK_CODE(BWD[i + 2]);
           const double *qbA = QB + i + 1;  // row i+2
           double g1 = 0.0, g2 = 0.0;
-          SF_PFL_BATCHES(30, 4, 9, {
+          SF_PFL_BATCHES(30, 4, 9, { ca[t] = SF_LANE_GET(tcol, 34 - u); pa[t] = SF_PK_ROW(SF_LANE_GET(tpk, 34 - u)); }, {
             const int u_ = 34 - u;  // ascending sizes 4..30
-            qa[t] = qbA[SF_LANE_GET(tcol, u_)]; fa[t] = f1N[SF_PK_ROW(SF_LANE_GET(tpk, u_))];
+            qa[t] = qbA[ca[t]]; fa[t] = f1N[pa[t]];
             da[t] = d1N2[u_]; wa[t] = WIL1N[u_];
           }, {
             const int u_ = 34 - u;
@@ -786,13 +795,20 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
               coff += m + t - 4;  // COFF(x+1) - COFF(x) = x - 4
               f[t] = *(const double *)((const char *)fW + sf_lane_read_i32(tbw[h], m + t - 1 - 64 * h));
             }
+            // (the trip's eight values of qm into scalar registers first, then the arithmetic: read where they are used, every
+            // v_readlane pair was followed by a hazard no-op before the multiply-add that takes it)
+            double gv[4][2];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+              gv[t][0] = sf_lane_read_f64(g[0][h], m + t - 1 - 64 * h);
+              gv[t][1] = sf_lane_read_f64(g[1][h], m + t - 1 - 64 * h);
+            }
             SF_SCHED_FENCE();
 #pragma unroll
             for (int t = 0; t < 4; t++) {
               const double w = q[t] * f[t];
-              const int cq = m + t - 1 - 64 * h;
-              racc[0] += w * sf_lane_read_f64(g[0][h], cq);
-              racc[1] += w * sf_lane_read_f64(g[1][h], cq);
+              racc[0] += w * gv[t][0];
+              racc[1] += w * gv[t][1];
             }
           }
           if (m <= mhi) {
@@ -905,8 +921,8 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
           } else {
             // (reads of a batch of sizes are issued together, then used: left to itself the compiler waits for almost
             // every LDS read on the spot — ~40 round trips in this block alone, and the column is nothing but such chains)
-            SF_PFL_BATCHES(30, 6, 9, {
-              qa[t] = qbA[SF_LANE_GET(tcol, u - 1)]; fa[t] = fI[SF_PK_ROW(SF_LANE_GET(tpk, u - 1))];
+            SF_PFL_BATCHES(30, 6, 9, { ca[t] = SF_LANE_GET(tcol, u - 1); pa[t] = SF_PK_ROW(SF_LANE_GET(tpk, u - 1)); }, {
+              qa[t] = qbA[ca[t]]; fa[t] = fI[pa[t]];
               da[t] = dI3[1 - u]; wa[t] = WN[u - 4];
             }, {
               const double a = qa[t] * fa[t];
@@ -950,12 +966,12 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
           const double *dB1 = DERP(2, l + 1) + k - 1;
           const double *qbA = QB + (k > 1 ? k - 2 : 0);  // row k-1 (row 1 for speculative reads)
           double gb = 0.0, gb2 = 0.0;
-          SF_PFL_BATCHES(30, 2, 10, {
+          SF_PFL_BATCHES(30, 2, 10, { ca[t] = SF_LANE_GET(tcol, 33 - u); pa[t] = SF_PK_NT(SF_LANE_GET(tpk, 33 - u)); }, {
             const int u_ = 32 - u;  // ascending sizes 2..30, as the sums were always accumulated
-            qa[t] = qbA[SF_LANE_GET(tcol, u_ + 1)]; da[t] = dB1[-u_]; wa[t] = WB[u_]; fa[t] = 0.0;
+            qa[t] = qbA[ca[t]]; da[t] = dB1[-u_]; wa[t] = WB[u_]; fa[t] = 0.0;
           }, {
             const int u_ = 32 - u;
-            const double ab = qa[t] * ((sp1 * SF_PK_NT(SF_LANE_GET(tpk, u_ + 1)) == 6) ? 1.0 : xTAU);
+            const double ab = qa[t] * ((sp1 * pa[t] == 6) ? 1.0 : xTAU);
             const double tt = (ab + da[t]) * wa[t];  // u1 = 0, u2 = 0
             if (u_ & 1) gb2 += tt; else gb += tt;
           })
@@ -981,9 +997,9 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
           const double *f1N = FAC + 625 + SF_PK_CODE(FWD[kr2]);
           const double *qbA = QB + kr2 - 1;
           double g1 = 0.0, g2 = 0.0;
-          SF_PFL_BATCHES(30, 4, 9, {
+          SF_PFL_BATCHES(30, 4, 9, { ca[t] = SF_LANE_GET(tcol, 34 - u); pa[t] = SF_PK_ROW(SF_LANE_GET(tpk, 34 - u)); }, {
             const int u_ = 34 - u;  // ascending sizes 4..30
-            qa[t] = qbA[SF_LANE_GET(tcol, u_)]; fa[t] = f1N[SF_PK_ROW(SF_LANE_GET(tpk, u_))];
+            qa[t] = qbA[ca[t]]; fa[t] = f1N[pa[t]];
             da[t] = d1N2[-u_]; wa[t] = WIL1N[u_];
           }, {
             const int u_ = 34 - u;

@@ -733,38 +733,11 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
       // index in the team + 1), fetches w(kf,m), m > r0, once and adds it to the sums of two of the block's columns — each team has
       // its two, no exchange —, each sum with its own row of qm, held a column per lane and read with v_readlane (entries the row
       // does not have, m < r+5, are zeros).  What a block cannot contain — the terms m = l+5 .. r0 of its last three columns, one to
-      // three per row — is added when the column comes (r1_part).  The owner of a column writes R1 before the barrier.
+      // three per row — is added when the column comes.  The owner of a column writes R1 before the barrier.
       const int rblk = (W - l) % SF_PFL_RB, r0 = l + rblk;
       const int nblk = sfd_max(l - 10 + 7, 0) >> 3;  // blocks of eight terms of the longest row's multiloop sum
       const int mlblk1 = sfd_min(sfd_max(l - SF_PFL_MLS0, 0) / SF_PFL_MLS1, nblk >> 1);
       const int mlsplit = 6 + 8 * (nblk - mlblk1);  // team 3: a < mlsplit, team 1: the rest
-      auto r1_part = [&](const int kr, int m, const int mhi) -> double {
-        double r1 = 0.0, r1b = 0.0;
-        const double *fW = FAC + 1250 + SF_PK_CODE(FWD[sfd_min(kr, W)]);
-        // (four terms per trip, their reads issued together; the neighbour codes — the address of a term's weight — are
-        // fetched one trip ahead)
-        int bw[4];
-#pragma unroll
-        for (int t = 0; t < 4; t++) bw[t] = BWD[sfd_min(m + t, W)];
-        for (; m + 3 <= mhi; m += 4) {
-          double q[4], f[4], g[4];
-          int bn[4];
-#pragma unroll
-          for (int t = 0; t < 4; t++) {
-            q[t] = QBC(kr, m + t);
-            f[t] = fW[SF_PK_ROW(bw[t])];
-            g[t] = QMD(m + t - 1 - l, l);
-            bn[t] = BWD[sfd_min(m + 4 + t, W)];
-          }
-          SF_SCHED_FENCE();
-          r1 += q[0] * f[0] * g[0] + q[2] * f[2] * g[2];
-          r1b += q[1] * f[1] * g[1] + q[3] * f[3] * g[3];
-#pragma unroll
-          for (int t = 0; t < 4; t++) bw[t] = bn[t];
-        }
-        for (; m <= mhi; m++) r1 += QBC(kr, m) * fW[SF_PK_ROW(BWD[m])] * QMD(m - 1 - l, l);
-        return r1 + r1b;
-      };
       auto r1_block = [&](const int kr, const int jb) {
         const int ln = tid & 63;
         double g[2][2];  // qm[l-jb-jj, c], column c = lane + 64 h (0 where the entry does not exist)
@@ -839,7 +812,25 @@ __global__ __launch_bounds__(SF_PFL_NT) void sf_pf_lds_kernel(const uint8_t *__r
         if (rblk == 0) r1_block(kf, jb);
         if ((rblk >> 1) == (jb >> 1)) {
           double r1v = (rblk & 1) ? racc[1] : racc[0];
-          if (rblk >= 5) r1v += r1_part(kf, l + SFD_TURN + 2, r0);
+          if (rblk >= 5) {
+            // the one to three terms m = l+5 .. r0 the block could not contain: their reads issued together, the row of the weight
+            // from the lane table (as a loop with an LDS read of the neighbour code per term: two dependent round trips per term in
+            // the columns where this team is the last to arrive)
+            const double *fW = FAC + 1250 + SF_PK_CODE(FWD[sfd_min(kf, W)]);
+            double q[3], f[3], gq[3];
+#pragma unroll
+            for (int t = 0; t < 3; t++) {
+              const int mt = sfd_min(l + SFD_TURN + 2 + t, r0);
+              const int o0 = sf_lane_read_i32(tbw[0], (mt - 1) & 63), o1 = sf_lane_read_i32(tbw[1], (mt - 1) & 63);
+              q[t] = QBC(kf, mt);
+              f[t] = *(const double *)((const char *)fW + (((mt - 1) >> 6) ? o1 : o0));
+              gq[t] = QMD(mt - 1 - l, l);
+            }
+            double r1 = 0.0;
+#pragma unroll
+            for (int t = 0; t < 3; t++) r1 += (l + SFD_TURN + 2 + t <= r0) ? q[t] * f[t] * gq[t] : 0.0;
+            r1v += r1;
+          }
           if (kf <= l - SFD_TURN - 1) R1n[kf] = r1v;
         }
       }

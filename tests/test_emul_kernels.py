@@ -101,6 +101,20 @@ def test_traceback_and_partition_function(emul, oracle):
             assert abs(o["centroid_dist"] - r["centroid_dist"][k]) < 1e-9
 
 
+def test_partition_function_at_the_lane_boundaries(emul, oracle):
+    """sf_pf_lds_kernel keeps per-column state a lane per column / row in two registers (columns 1..64 and 65..128): the exterior
+    walks and the blocked R1 sums change register at 64 / 65, the exterior-loop table moves between two LDS areas at W = 92.
+    Widths on both sides of each boundary against the oracle (the GPU every-width sweep covers all of 16..256 on hardware)."""
+    rng = np.random.default_rng(64)
+    for W in (63, 64, 65, 66, 91, 92, 100):
+        arr = random_seqs(rng, 2, W)
+        r = emul.pf_batch(arr)
+        for k in range(len(arr)):
+            o = oracle.pf(bytes(arr[k]).decode())
+            assert abs(o["dG"] - r["dG"][k]) < 1e-9 and o["centroid"] == r["centroid"][k], (W, k)
+            assert abs(o["mean_bp_dist"] - r["mean_bp_dist"][k]) < 1e-9 and abs(o["centroid_dist"] - r["centroid_dist"][k]) < 1e-9, (W, k)
+
+
 def test_randomised_tables_catch_index_order(emul):
     from oracle import oracle as orc
     rng = np.random.default_rng(2)
